@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- ms per 2^20-point BLS12-377 G1 MSM on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole MSM over the synthetic workload of BASELINE.md section 3 (configs[1]):
+n = 2^20 points P_i = [a_i]G (a_i = SplitMix64(0x377), generated on the GPU by the engine),
+scalars uniform below r from SplitMix64(0x5ca1a5); wire format of the reference harness
+(src/ui/AllBenchmarks.tsx:57-68).  Inputs are resident in HBM when the timed region starts;
+every step runs convert -> decompose -> sort -> accumulate -> reduce -> D2H of the partial
+records -> host Horner + inversion and ends with the affine result on the host, like the
+reference's timing bracket (src/ui/Benchmark.tsx:31-34).
+
+N > 1: the 16 window subtasks are sharded over the ranks (rank g owns a contiguous block of
+windows, no data-path collective), followed by ONE RCCL all-gather of the partial records and
+the Horner combine -- the same 2^20-point problem on more GPUs, so "scaling" is "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket accumulation) with
+HIP-event timings taken by the engine on its own stream; `cpu_baseline` times the CPU oracle
+(a port of the reference pipeline, not the reference's WASM) on the same inputs on this host
+and doubles as a full-size bit-exactness check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_ORDER = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+LOG_N = 20
+NUM_WINDOWS = 16
+NUM_BUCKETS = 32768
+
+
+def algorithmic_bytes(n):
+    """B_alg(n) = 32n + 96n + W*96n + 2*W*2^15*144 + 96 (whole MSM), and the
+    share of the bucket-accumulation launch: W*96n gathered + W*2^15*144 written."""
+    whole = 32 * n + 96 * n + NUM_WINDOWS * 96 * n + 2 * NUM_WINDOWS * NUM_BUCKETS * 144 + 96
+    accumulate = NUM_WINDOWS * 96 * n + NUM_WINDOWS * NUM_BUCKETS * 144
+    return whole, accumulate
+
+
+def seeded_scalars(seed, n):
+    """n scalars uniform below r: four SplitMix64 outputs per scalar, reduced mod r (identical to
+    tests/pyref.py:rand_scalars)."""
+    import numpy as np
+
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, 4 * n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    raw = z.astype("<u8").tobytes()
+    out = bytearray(32 * n)
+    for i in range(n):
+        v = int.from_bytes(raw[32 * i : 32 * i + 32], "little") % R_ORDER
+        out[32 * i : 32 * i + 32] = v.to_bytes(32, "little")
+    return bytes(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 of the point count (default 20: the metric's workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import webgpu_msm_bls12_377_amd as msm
+    from webgpu_msm_bls12_377_amd.host.sharding import sharded_msm, windows_for_rank
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.log_n
+    eng = msm.MsmEngine(n, device=local_rank)
+    d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
+    eng.generate_bases_device(0x377, n, d_points.data_ptr())
+    scalars_host = seeded_scalars(0x5CA1A5, n)
+    d_scalars = torch.frombuffer(bytearray(scalars_host), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    pp, sp = d_points.data_ptr(), d_scalars.data_ptr()
+    dev = torch.device("cuda", local_rank)
+
+    def step():
+        if world == 1:
+            return eng.msm_device(pp, sp, n)
+        return sharded_msm(lambda b, c: eng.window_partials_device(pp, sp, n, b, c), rank, world, device=dev)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    eng.set_timing(True)
+    stage_sum = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        for k, v in eng.stage_ms().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.set_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / max(1, args.steps)
+    stages = {k: v / max(1, args.steps) for k, v in stage_sum.items()}
+
+    out = None
+    if rank == 0:
+        whole_bytes, acc_bytes = algorithmic_bytes(n)
+        _, my_windows = windows_for_rank(rank, world)
+        acc_ms = stages.get("accumulate", 0.0)
+        acc_bytes_launch = acc_bytes * my_windows / NUM_WINDOWS  # one launch covers this rank's windows
+        achieved = acc_bytes_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        out = {
+            "metric": "ms per 2^%d BLS12-377 G1 MSM" % args.log_n,
+            "value": round(ms_per_step, 4),
+            "unit": "ms",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32 (29-bit limbs, 64-bit accumulate)",
+            "data": "synthetic",
+            "config": {
+                "workload": "2^%d BLS12-377 G1 (short Weierstrass) MSM, 16-bit signed windows, inputs resident in HBM" % args.log_n,
+                "points": "P_i=[a_i]G, a_i=SplitMix64(0x377)",
+                "scalars": "uniform < r, SplitMix64(0x5ca1a5)",
+                "parallelism": "windows sharded over %d GPU(s), one RCCL all-gather" % world if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_accumulate (bucket accumulation)",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": int(acc_bytes_launch),
+                "kernel_ms": round(acc_ms, 4),
+            },
+            "whole_job_hbm_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "result_x": hex(int.from_bytes(result[:48], "little")),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # PCIe-inclusive figure for DESIGN.md (never `value`): host buffers in, result out
+            points_host = d_points.cpu().numpy().tobytes()
+            t1 = time.perf_counter()
+            r2 = eng.msm(points_host, scalars_host)
+            out["ms_incl_h2d"] = round((time.perf_counter() - t1) * 1e3, 3)
+            assert r2 == result
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import util  # the CPU oracle: checker + cpu_baseline leg only
+
+            oracle = util.load_oracle()
+            t1 = time.perf_counter()
+            cpu = util.oracle_msm(oracle, points_host, scalars_host)
+            cpu_ms = (time.perf_counter() - t1) * 1e3
+            if cpu != result:
+                raise SystemExit("PARITY FAILURE: HIP result differs from the CPU oracle at n=2^%d" % args.log_n)
+            out["cpu_baseline"] = {
+                "value": round(cpu_ms, 1),
+                "unit": "ms per 2^%d MSM" % args.log_n,
+                "cores": int(oracle.oracle_omp_threads()),
+                "kind": "port",
+                "sample": "the full 2^%d workload, 1 run, same inputs; result bit-exact with the GPU's" % args.log_n,
+            }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

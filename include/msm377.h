@@ -1,0 +1,130 @@
+/*
+ * msm377 -- C ABI of the MI355X (gfx950) multi-scalar-multiplication engine.
+ *
+ * This is the drop-in boundary for the reference's hot path
+ *     compute_msm(baseAffinePoints: Buffer, scalars: Buffer) -> {x, y}
+ *     (/root/reference: src/submission/submission.ts:85-90, called from src/ui/Benchmark.tsx:32
+ *      and src/submission/miscellaneous/full_benchmarks.ts:62,99).
+ * An N-API shim (webgpu-msm-bls12-377_amd/node/) and a ctypes mirror
+ * (webgpu-msm-bls12-377_amd/host/) bind exactly these entry points; see INTEGRATION.md.
+ *
+ * Wire format (unchanged from the reference harness, src/ui/AllBenchmarks.tsx:57-68 and
+ * src/reference/webgpu/utils.ts:63-72):
+ *   points   n x 96 bytes : x as 48-byte little-endian || y as 48-byte little-endian,
+ *                           canonical residues < p, affine, never the point at infinity
+ *   scalars  n x 32 bytes : little-endian integers < 2^255 - 2^239 (the reference requires
+ *                           "no final carry" in the signed recode, cuzk/utils.ts:95-98)
+ *   result   96 bytes     : affine x || y, 48-byte little-endian each; the identity (and the
+ *                           empty input) is x = 0, y = 1 (submission.ts:93-95)
+ *
+ * All functions return 0 on success or a negative MSM377_E* code; none of them throws or
+ * aborts.  A context is not thread-safe: one call in flight per context (the reference has one
+ * caller thread).  There is NO CPU fallback: without a usable HIP
+ * device every entry point that needs one fails with MSM377_EHIP.
+ */
+#ifndef MSM377_H
+#define MSM377_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSM377_OK 0
+#define MSM377_EINVAL (-1)    /* bad argument (null pointer, n over capacity, window range) */
+#define MSM377_EHIP (-2)      /* a HIP runtime call failed; see msm377_last_error() */
+#define MSM377_ESCALAR (-3)   /* a scalar overflowed the signed 16-bit recode (final carry) */
+#define MSM377_ENOMEM (-4)    /* device or host allocation failed */
+#define MSM377_ESTATE (-5)    /* call sequence error (e.g. fixed-base MSM before set_bases) */
+
+#define MSM377_NUM_WINDOWS 16          /* ceil(256 / 16): submission.ts:108-109 */
+#define MSM377_WINDOW_BITS 16          /* chunk_size for n >= 2^16: submission.ts:97 */
+/* One window's partial result: 16 points (plain bucket sum + 15 bit-plane sums), each four
+ * 13-word Montgomery coordinates (X, Y, ZZ, ZZZ). */
+#define MSM377_G1_PARTIAL_POINTS 16
+#define MSM377_G1_POINT_WORDS 52
+#define MSM377_G1_WINDOW_PARTIAL_BYTES (MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS * 4)
+
+typedef struct msm377_ctx msm377_ctx;
+
+/* Library / build identification, e.g. "msm377 0.1 gfx950". */
+const char* msm377_version(void);
+/* Text for a MSM377_E* code. */
+const char* msm377_strerror(int code);
+
+/* Create a context on HIP device `device` with workspace for up to `max_points` inputs
+ * (replaces get_device + the per-call buffer creation, cuzk/gpu.ts:2-52; unlike the reference
+ * the device state persists across calls until msm377_ctx_destroy). */
+int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out);
+void msm377_ctx_destroy(msm377_ctx* ctx);
+/* Last HIP / argument error text for this context ("" if none). */
+const char* msm377_last_error(const msm377_ctx* ctx);
+
+/* ---- BLS12-377 G1 (short Weierstrass y^2 = x^3 + 1) ------------------------------------ */
+
+/* compute_msm with host buffers: uploads, runs the pipeline, returns the affine result.
+ * Replaces submission.ts:85-327 end to end. */
+int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]);
+
+/* Same with inputs already in device memory (same wire format).  This is the variant timed
+ * by bench.py ("inputs resident in HBM"). */
+int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[96]);
+
+/* Fixed-base batches (BASELINE.json config 5): convert and keep a base set in HBM once ... */
+int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
+int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n);
+/* ... then run any number of MSMs of n scalars (host or device pointer) against it. */
+int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]);
+int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint8_t out_xy[96]);
+
+/* Window sharding for multi-GPU runs (the reference already treats the
+ * 16 window subtasks as independent, submission.ts:199-224).  Computes windows
+ * [win_begin, win_begin + win_count) only and writes win_count partial records of
+ * MSM377_G1_WINDOW_PARTIAL_BYTES each to the HOST buffer partials_out. */
+int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n,
+                                     uint32_t win_begin, uint32_t win_count, uint8_t* partials_out);
+/* Combine the partial records of all MSM377_NUM_WINDOWS windows (window-major, gathered from
+ * the ranks) into the final affine result: Horner over the windows, one field inversion.
+ * Host-only; needs no context and no device (replaces the CPU tail, submission.ts:290-321). */
+int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
+
+/* Synthetic inputs: P_i = [a_i]G, a_i the i-th SplitMix64(seed)
+ * output, written in wire format to device memory d_points_out (n x 96 bytes). */
+int msm377_g1_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out);
+
+/* ---- stage access for parity tests (the reference's debug=true read-backs,
+ *      submission.ts:466-520, 613-641, 724-798) ------------------------------------------- */
+
+/* After any g1 MSM call: copy stage outputs of window slot `slot` (0-based within the windows
+ * computed by the last call) to host buffers; any pointer may be NULL.
+ *   digits   n u16          biased signed digits, d + 2^15
+ *   row_ptr  32770 u32      CSR offsets over keys |d| = 0..32768 (key 0 = digit 0)
+ *   val_idx  n u32          point index | (sign << 31), grouped by key
+ *   buckets  32768 x 52 u32 bucket t = 1..32768 at row t-1: X, Y, ZZ, ZZZ (13 Montgomery words
+ *                           each) as left by bucket accumulation
+ * Only valid when the context was created with stage capture enabled. */
+int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled);
+int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint32_t* row_ptr, uint32_t* val_idx, uint32_t* buckets);
+/* Convert one Montgomery XYZZ point (52 words) to the affine wire format (host-only). */
+int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+#define MSM377_STAGE_CONVERT 0     /* points -> Montgomery records */
+#define MSM377_STAGE_DECOMPOSE 1   /* scalars -> signed 16-bit digits */
+#define MSM377_STAGE_SORT 2        /* histogram + scan + scatter (CSR build) */
+#define MSM377_STAGE_ACCUMULATE 3  /* bucket accumulation (SMVP) -- the dominant kernel */
+#define MSM377_STAGE_REDUCE 4      /* bucket reduction tree */
+#define MSM377_STAGE_TAIL 5        /* D2H of the partial records + host Horner/inversion */
+#define MSM377_NUM_STAGES 6
+/* Enable HIP-event timing of every stage on the context's stream (off by default). */
+int msm377_ctx_set_timing(msm377_ctx* ctx, int enabled);
+/* Durations in milliseconds of the last call's stages (MSM377_NUM_STAGES entries; the TAIL
+ * entry is host wall time). */
+int msm377_ctx_get_stage_ms(msm377_ctx* ctx, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM377_H */

@@ -1,0 +1,101 @@
+"""The product's device math headers (csrc/field29.hpp, g1_xyzz.hpp, fp64_host.hpp) compiled for the
+host and checked against Python big integers.  CPU only.  The same headers compile into the HIP
+kernels; csrc/microbench.hip checks device == host on the GPU."""
+import ctypes
+import os
+import random
+import struct
+import subprocess
+
+import pytest
+
+import pyref as R
+import util
+
+ROOT = util.ROOT
+CSRC = os.path.join(ROOT, "webgpu-msm-bls12-377_amd", "csrc")
+SHIM_SRC = os.path.join(ROOT, "tests", "native", "field29_shim.cpp")
+SHIM_SO = os.path.join(ROOT, "tests", "native", "_build", "libfield29_shim.so")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    deps = [SHIM_SRC] + [os.path.join(CSRC, f) for f in ("field29.hpp", "g1_xyzz.hpp", "fp64_host.hpp", "consts_gen.hpp")]
+    if not os.path.exists(SHIM_SO) or any(os.path.getmtime(d) > os.path.getmtime(SHIM_SO) for d in deps):
+        os.makedirs(os.path.dirname(SHIM_SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I", CSRC, "-o", SHIM_SO, SHIM_SRC])
+    return ctypes.CDLL(SHIM_SO)
+
+
+def words12(v):
+    return (ctypes.c_uint32 * 12)(*[(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)])
+
+
+def from_words(arr):
+    return sum(int(w) << (32 * i) for i, w in enumerate(arr))
+
+
+def test_field_ops(shim):
+    rnd = random.Random(377)
+    special = [0, 1, 2, R.P - 1, R.P - 2, (1 << 376), (1 << 29) - 1, 1 << 29, (R.P - 1) // 2, (1 << 348) - 1, R.P - (1 << 348)]
+    vals = special + [rnd.randrange(R.P) for _ in range(400)]
+    for it in range(1500):
+        a, b = (rnd.choice(vals), rnd.choice(vals)) if it >= len(special) ** 2 else (special[it // len(special)], special[it % len(special)])
+        outs = [(ctypes.c_uint32 * 12)() for _ in range(5)]
+        shim.shim_fp_ops(words12(a), words12(b), *outs)
+        got = [from_words(o) for o in outs]
+        assert got == [a * b % R.P, (a + b) % R.P, (a - b) % R.P, a * a % R.P, (-a) % R.P], (a, b)
+
+
+def test_montgomery_limb_format(shim):
+    rnd = random.Random(1)
+    for v in [0, 1, R.P - 1] + [rnd.randrange(R.P) for _ in range(50)]:
+        limbs = (ctypes.c_uint32 * 13)()
+        shim.shim_fp_to_mont_limbs(words12(v), limbs)
+        assert list(limbs) == util.to_limbs29_mont(v)
+        assert all(x < (1 << 29) for x in limbs)
+
+
+def xyzz_buf(pt, z=1):
+    """XYZZ words of an affine point scaled by a projective factor z (ZZ = z^2, ZZZ = z^3)."""
+    if pt is None:
+        return (ctypes.c_uint32 * 52)(*util.xyzz_words_from_affine(None))
+    x, y = pt
+    zz, zzz = z * z % R.P, z * z * z % R.P
+    w = util.to_limbs29_mont(x * zz % R.P) + util.to_limbs29_mont(y * zzz % R.P) + util.to_limbs29_mont(zz) + util.to_limbs29_mont(zzz)
+    return (ctypes.c_uint32 * 52)(*w)
+
+
+def xy24(pt):
+    return (ctypes.c_uint32 * 24)(*([(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(12)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(12)]))
+
+
+def test_curve_ops_including_special_cases(shim):
+    rnd = random.Random(5)
+    pts = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(12)]
+    out = (ctypes.c_uint32 * 52)()
+    cases = []
+    for _ in range(60):
+        cases.append((rnd.choice(pts), rnd.choice(pts)))
+    cases += [(p, p) for p in pts[:4]] + [(p, R.neg(p)) for p in pts[:4]] + [(None, p) for p in pts[:3]]
+    for a, b in cases:
+        z1, z2 = rnd.randrange(1, R.P), rnd.randrange(1, R.P)
+        # mixed add
+        shim.shim_g1_madd(xyzz_buf(a, z1), xy24(b), out)
+        assert util.affine_from_xyzz_words(list(out)) == R.add(a, b), ("madd", a, b)
+        # general add, both operands with non-trivial ZZ/ZZZ, both orders
+        shim.shim_g1_add(xyzz_buf(a, z1), xyzz_buf(b, z2), out)
+        assert util.affine_from_xyzz_words(list(out)) == R.add(a, b), ("add", a, b)
+        shim.shim_g1_add(xyzz_buf(b, z2), xyzz_buf(a, z1), out)
+        assert util.affine_from_xyzz_words(list(out)) == R.add(a, b)
+        shim.shim_g1_add(xyzz_buf(b, z2), xyzz_buf(None), out)
+        assert util.affine_from_xyzz_words(list(out)) == b
+        # doubling
+        shim.shim_g1_dbl(xyzz_buf(b, z2), out)
+        assert util.affine_from_xyzz_words(list(out)) == R.add(b, b)
+        # host-tail field (64-bit words) through the same template
+        w = ctypes.create_string_buffer(96)
+        shim.shim_g1h_add_to_wire(xyzz_buf(a, z1), xyzz_buf(b, z2), w)
+        assert w.raw == R.encode_result(R.add(a, b))
+    shim.shim_g1_dbl(xyzz_buf(None), out)
+    assert util.affine_from_xyzz_words(list(out)) is None

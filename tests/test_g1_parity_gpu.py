@@ -1,0 +1,255 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI (ctypes mirror), against the
+CPU oracle on the same seeded inputs, the committed golden vectors, and -- at the full 2^20 size --
+a closed-form property.  Run on an MI355X with `pytest -m gpu`.
+
+Bar: bit-exact (integer work).  Shapes follow the reference's own checks: end-to-end result
+(src/ui/Benchmark.tsx:41-48) and the per-stage debug read-backs (src/submission/submission.ts:466-520,
+613-641, 724-798).
+"""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import pyref as R
+import util
+import webgpu_msm_bls12_377_amd as msm
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(buf: bytes):
+    """bytes -> uint8 tensor in HBM (torch is plumbing for device memory only)."""
+    import torch
+
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+
+
+def seeded_inputs(oracle, n, seed):
+    rnd = random.Random(seed)
+    pts = util.oracle_gen_points(oracle, n, rnd.randrange(1, 1 << 200), rnd.randrange(1, 1 << 200))
+    ks = R.encode_scalars(R.rand_scalars(seed, n))
+    return pts, ks
+
+
+def test_golden_vectors(engine, golden):
+    for name, case in golden.items():
+        assert engine.msm(case["points"], case["scalars"]) == case["expected"], name
+
+
+def test_compute_msm_entry_point(golden):
+    """Same call shapes as the reference's callers (Benchmark.tsx:32; full_benchmarks.ts:62)."""
+    case = golden["g1_n33_random"]
+    exp = R.decode_result(case["expected"])
+    res = msm.compute_msm(case["points"], case["scalars"], log_result=False)
+    assert res == {"x": exp[0], "y": exp[1]}
+    pts = [{"x": x, "y": y, "z": 1} for x, y in R.decode_points(case["points"])]
+    assert msm.compute_msm(pts, R.decode_scalars(case["scalars"]), False) == res
+    u32pts = [{"x": msm.bigIntToU32Array(p["x"], 384), "y": msm.bigIntToU32Array(p["y"], 384)} for p in pts]
+    u32ks = [msm.bigIntToU32Array(k) for k in R.decode_scalars(case["scalars"])]
+    assert msm.compute_msm(u32pts, u32ks, False) == res
+    assert msm.compute_msm(b"", b"", False) == {"x": 0, "y": 1}  # submission.ts:93-95
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 257, 1000, 4097, 10007])
+def test_ragged_sizes_against_oracle(engine, oracle, n):
+    pts, ks = seeded_inputs(oracle, n, 100 + n)
+    assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+
+
+def test_2_16_against_reference_sized_oracle(engine, oracle):
+    """BASELINE.json configs[0] size: the oracle runs the reference's production parameters
+    (16-bit windows, 256 BPR threads) on 2^16 points."""
+    n = 1 << 16
+    pts, ks = seeded_inputs(oracle, n, 16)
+    exp = util.oracle_msm(oracle, pts, ks)
+    assert engine.msm(pts, ks) == exp
+    d_p, d_s = dev(pts), dev(ks)
+    assert engine.msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == exp
+
+
+def test_stage_parity(engine, oracle):
+    """Decomposition, CSR and bucket sums against the oracle's stage functions."""
+    n = 5000
+    pts, ks = seeded_inputs(oracle, n, 4242)
+    engine.set_stage_capture(True)
+    try:
+        res = engine.msm(pts, ks)
+        assert res == util.oracle_msm(oracle, pts, ks)
+        chunks = np.zeros(16 * n, dtype=np.uint32)
+        assert oracle.oracle_decompose_scalars_signed(ks, n, 16, chunks.ctypes.data) == 0
+        chunks = chunks.reshape(16, n)
+        rp_o = np.zeros(16 * 65537, dtype=np.uint32)
+        vi_o = np.zeros(16 * n, dtype=np.uint32)
+        oracle.oracle_cpu_transpose(chunks.ctypes.data, n, 65536, 16, rp_o.ctypes.data, vi_o.ctypes.data)
+        for slot in (0, 7, 15):
+            st = engine.read_stage(slot, n)
+            # a4/a5: biased signed digits identical to decompose_scalars_signed
+            assert np.array_equal(st["digits"].astype(np.uint32), chunks[slot])
+            # a6: row t of the folded CSR holds exactly the points of digits +t and -t
+            rp, vi = st["row_ptr"], st["val_idx"]
+            assert rp[0] == 0 and rp[-1] == n and np.all(np.diff(rp.astype(np.int64)) >= 0)
+            rpo = rp_o[slot * 65537 : (slot + 1) * 65537]
+            vio = vi_o[slot * n : (slot + 1) * n]
+            for key in list(range(0, 40)) + [32767, 32768] + random.Random(slot).sample(range(40, 32767), 200):
+                got = sorted((int(e) & 0x7FFFFFFF, int(e) >> 31) for e in vi[rp[key] : rp[key + 1]])
+                pos = [(int(i), 0) for i in vio[rpo[32768 + key] : rpo[32768 + key + 1]]] if key < 32768 else []
+                negs = [(int(i), 1) for i in vio[rpo[32768 - key] : rpo[32768 - key + 1]]] if key > 0 else []
+                assert got == sorted(pos + negs), (slot, key)
+            # a7: bucket sums equal the WGSL semantics (bucket t-1 here = thread id t there; id 0 = digit -2^15)
+            bo = ctypes.create_string_buffer(96 * 32768)
+            assert oracle.oracle_g1_smvp_window(pts, ks, n, 16, slot, ctypes.addressof(bo)) == 0
+            bk = st["buckets"]
+            nonempty = 0
+            for t in range(1, 32769):
+                exp = bo.raw[96 * (t % 32768) : 96 * (t % 32768) + 96]
+                words = bk[t - 1]
+                if not words[26:39].any():  # ZZ = 0: identity
+                    assert exp == R.encode_result(None), (slot, t)
+                    continue
+                nonempty += 1
+                if nonempty <= 400:  # full big-integer check on the first few hundred non-empty buckets
+                    assert R.encode_result(util.affine_from_xyzz_words(words)) == exp, (slot, t)
+            assert nonempty > 1000
+    finally:
+        engine.set_stage_capture(False)
+
+
+def test_bucket_boundaries_and_signs(engine, oracle):
+    """Digits hitting 0, +-1, +2^15-1, -2^15 in every window; repeated and opposite points."""
+    g = R.G
+    p2 = R.mul(g, 2)
+    pts = [g, g, R.neg(g), p2, R.neg(p2), g, p2, g]
+    full = lambda d: sum((d & 0xFFFF) << (16 * w) for w in range(15))  # noqa: E731
+    ks = [full(0x8000), full(0x8000), full(0x8000), full(0x7FFF), full(0x7FFF), full(1), full(0xFFFF) % R.R_ORDER, 0]
+    pb, sb = R.encode_points(pts), R.encode_scalars(ks)
+    exp = R.encode_result(R.msm_naive(pts, ks))
+    assert engine.msm(pb, sb) == exp == util.oracle_msm(oracle, pb, sb, "oracle_g1_msm_naive")
+
+
+def test_one_repeated_base_point(engine, oracle):
+    """The harness's 'random inputs' mode: ONE base point repeated (src/ui/AllBenchmarks.tsx:84-88),
+    so every bucket with two entries doubles."""
+    n = 3000
+    pts = R.encode_points([R.FIXED_BASE]) * n
+    ks = R.encode_scalars(R.rand_scalars(31337, n))
+    total = sum(R.decode_scalars(ks)) % R.R_ORDER
+    exp = R.encode_result(R.mul(R.FIXED_BASE, total))
+    assert engine.msm(pts, ks) == exp
+
+
+def test_all_same_scalar(engine, oracle):
+    """Maximally skewed buckets: every point lands in the same bucket of each window."""
+    n = 2048
+    pts, _ = seeded_inputs(oracle, n, 77)
+    k = R.rand_scalars(78, 1)[0]
+    ks = R.encode_scalars([k] * n)
+    assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+
+
+def test_scalar_overflow_is_an_error(engine, golden):
+    """cuzk/utils.ts:95-98 throws "final carry is 1"; here MSM377_ESCALAR."""
+    case = golden["g1_n1_gen"]
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm(case["points"], ((1 << 256) - 1).to_bytes(32, "little"))
+    assert e.value.code == -3
+    assert engine.msm(case["points"], case["scalars"]) == case["expected"]  # context still usable
+
+
+def test_argument_errors(engine, golden):
+    case = golden["g1_n33_random"]
+    with pytest.raises(ValueError):
+        engine.msm(case["points"][:-1], case["scalars"])
+    d_p, d_s = dev(case["points"]), dev(case["scalars"])
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm_device(d_p.data_ptr() + 4, d_s.data_ptr(), 32)
+    assert e.value.code == -1
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm_device(d_p.data_ptr(), d_s.data_ptr(), engine.max_points + 1)
+    assert e.value.code == -1
+    with pytest.raises(msm.MsmError) as e:
+        engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), 33, 15, 2)
+    assert e.value.code == -1
+
+
+def test_fixed_base_batches(engine, oracle):
+    """BASELINE.json config 5 in small: bases converted once and kept in HBM, several scalar sets."""
+    n = 3000
+    pts, _ = seeded_inputs(oracle, n, 5)
+    engine.set_bases(pts)
+    for s in range(4):
+        ks = R.encode_scalars(R.rand_scalars(900 + s, n))
+        assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
+    ks = R.encode_scalars(R.rand_scalars(1, 100))  # a prefix of the bases
+    assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts[: 96 * 100], ks)
+    engine.msm(pts[:96], ks[:32])  # a plain MSM invalidates the resident set
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm_fixed_base(ks)
+    assert e.value.code == -5
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8, 3])
+def test_window_sharding_on_one_gpu(engine, oracle, world):
+    """BASELINE.json config 4's data path with every rank's window block run on this one GPU: the
+    gathered partial records combine to the oracle's result (the RCCL gather itself is covered by
+    tests/test_sharding_gloo.py and bench.py --gpus N)."""
+    n = 6000
+    pts, ks = seeded_inputs(oracle, n, 88)
+    d_p, d_s = dev(pts), dev(ks)
+    parts = []
+    for r in range(world):
+        b, c = msm.windows_for_rank(r, world)
+        parts.append(engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, b, c))
+    assert msm.combine_partials(b"".join(parts)) == util.oracle_msm(oracle, pts, ks)
+
+
+def test_sharded_msm_single_rank(engine, oracle):
+    from webgpu_msm_bls12_377_amd.host.sharding import sharded_msm
+
+    n = 2000
+    pts, ks = seeded_inputs(oracle, n, 99)
+    d_p, d_s = dev(pts), dev(ks)
+    out = sharded_msm(lambda b, c: engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, b, c), 0, 1)
+    assert out == util.oracle_msm(oracle, pts, ks)
+
+
+def test_generate_bases(engine):
+    """Synthetic inputs P_i = [a_i]G, a_i = SplitMix64(seed)."""
+    import torch
+
+    n, seed = 40, 0x377
+    out = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
+    engine.generate_bases_device(seed, n, out.data_ptr())
+    got = R.decode_points(out.cpu().numpy().tobytes())
+    g = R.splitmix64(seed)
+    assert got == [R.mul(R.G, next(g)) for _ in range(n)]
+
+
+def test_full_size_2_20_closed_form(engine, oracle):
+    """BASELINE.json configs[1] size.  P_i = [a0 + i d]G, so sum k_i P_i = [sum k_i (a0 + i d) mod r]G:
+    one oracle scalar multiplication checks the whole 2^20-point MSM."""
+    n = 1 << 20
+    a0, d = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA
+    pts = util.oracle_gen_points(oracle, n, a0, d)
+    ks_int = R.rand_scalars(0x5CA1A5, n)
+    ks = R.encode_scalars(ks_int)
+    total = sum(k * (a0 + i * d) for i, k in enumerate(ks_int)) % R.R_ORDER
+    exp = ctypes.create_string_buffer(96)
+    gen = ctypes.create_string_buffer(96)
+    oracle.oracle_g1_generator(ctypes.addressof(gen))
+    assert oracle.oracle_g1_scalar_mul(gen.raw, total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
+    d_p, d_s = dev(pts), dev(ks)
+    engine.set_timing(True)
+    try:
+        got = engine.msm_device(d_p.data_ptr(), d_s.data_ptr(), n)
+        print("stage ms:", engine.stage_ms())
+    finally:
+        engine.set_timing(False)
+    assert got == exp.raw
+    # linearity on the same resident inputs: MSM(P, 2k) == 2 MSM(P, k) via the fixed-base path
+    engine.set_bases_device(d_p.data_ptr(), n)
+    ks2 = R.encode_scalars([(2 * k) % R.R_ORDER for k in ks_int])
+    exp2 = ctypes.create_string_buffer(96)
+    assert oracle.oracle_g1_scalar_mul(gen.raw, ((2 * total) % R.R_ORDER).to_bytes(32, "little"), 32, ctypes.addressof(exp2)) == 0
+    assert engine.msm_fixed_base(ks2) == exp2.raw

@@ -1,0 +1,60 @@
+"""Host-only entry points of the C ABI (no GPU needed): msm377_g1_combine_partials and
+msm377_g1_xyzz_to_affine -- the replacement of the reference's CPU tail
+(src/submission/submission.ts:290-321).  CPU only."""
+import random
+import struct
+
+import pytest
+
+import pyref as R
+import util
+import webgpu_msm_bls12_377_amd as msm
+from webgpu_msm_bls12_377_amd.host import engine as E
+
+
+def record(points16):
+    words = []
+    for pt in points16:
+        words += util.xyzz_words_from_affine(pt)
+    return struct.pack("<%dI" % len(words), *words)
+
+
+def test_xyzz_to_affine():
+    rnd = random.Random(2)
+    for _ in range(10):
+        pt = R.mul(R.G, rnd.randrange(1, R.R_ORDER))
+        z = rnd.randrange(1, R.P)
+        zz, zzz = z * z % R.P, z * z * z % R.P
+        words = util.to_limbs29_mont(pt[0] * zz % R.P) + util.to_limbs29_mont(pt[1] * zzz % R.P) + util.to_limbs29_mont(zz) + util.to_limbs29_mont(zzz)
+        assert E.xyzz_to_affine(words) == R.encode_result(pt)
+    assert E.xyzz_to_affine(util.xyzz_words_from_affine(None)) == R.encode_result(None)
+
+
+def test_combine_matches_definition():
+    """result = sum_w 2^(16 w) * (Sum_w + sum_l 2^l Plane_{w,l})."""
+    rnd = random.Random(3)
+    base = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(9)]
+    recs, expect = [], None
+    for w in range(16):
+        pts16 = [rnd.choice(base + [None]) for _ in range(16)]
+        recs.append(record(pts16))
+        g = pts16[0]
+        for l in range(15):
+            g = R.add(g, R.mul(pts16[1 + l], 1 << l))
+        expect = R.add(expect, R.mul(g, 1 << (16 * w)))
+    assert msm.combine_partials(b"".join(recs)) == R.encode_result(expect)
+
+
+def test_combine_against_oracle_window_sums(oracle, golden):
+    """Window sums from the oracle (submission.ts:297-308) fed through the product's host combine
+    reproduce the oracle's Horner result (submission.ts:310-318)."""
+    for name in ("g1_n33_random", "g1_n20_edge_scalars", "g1_n2_cancel"):
+        case = golden[name]
+        res, ws = util.oracle_msm_params(oracle, case["points"], case["scalars"], 16, 256, want_windows=True)
+        recs = b"".join(util.partial_record_from_window_sum(R.decode_result(ws[96 * w : 96 * w + 96])) for w in range(16))
+        assert msm.combine_partials(recs) == res == case["expected"]
+
+
+def test_combine_rejects_wrong_length():
+    with pytest.raises(ValueError):
+        msm.combine_partials(b"\0" * 100)

@@ -1,0 +1,82 @@
+"""Multi-GPU path on CPU: world_size-2 (and 3) gloo runs of the window sharding + all-gather +
+host combine.  The per-rank window work is done by the ORACLE here (no GPU in
+this container); on the GPU box the same sharded_msm() is driven by MsmEngine.window_partials_device
+(tests/test_g1_parity_gpu.py, bench.py).  CPU only."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+import util
+import webgpu_msm_bls12_377_amd as msm
+
+
+def test_windows_for_rank_covers_all_windows():
+    for world in range(1, 20):
+        seen = []
+        for r in range(world):
+            b, c = msm.windows_for_rank(r, world)
+            seen += list(range(b, b + c))
+        assert seen == list(range(16)), world
+    assert msm.windows_for_rank(0, 1) == (0, 16)
+    assert msm.windows_for_rank(7, 8) == (14, 2)
+    with pytest.raises(ValueError):
+        msm.windows_for_rank(3, 3)
+
+
+def _worker(rank, world, port, case_name, q):
+    import pyref as R
+    import torch.distributed as dist
+    from webgpu_msm_bls12_377_amd.host.sharding import sharded_msm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle = util.load_oracle()
+        case = util.load_golden()[case_name]
+        _, ws = util.oracle_msm_params(oracle, case["points"], case["scalars"], 16, 256, want_windows=True)
+
+        def partials_fn(begin, count):
+            return b"".join(util.partial_record_from_window_sum(R.decode_result(ws[96 * w : 96 * w + 96])) for w in range(begin, begin + count))
+
+        out = sharded_msm(partials_fn, rank, world, device="cpu")
+        q.put((rank, out == case["expected"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,case", [(2, "g1_n33_random"), (3, "g1_n20_edge_scalars")])
+def test_sharded_msm_gloo(world, case):
+    util.load_oracle()  # build once before forking
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def test_single_rank_needs_no_process_group(oracle, golden):
+    import pyref as R
+    from webgpu_msm_bls12_377_amd.host.sharding import sharded_msm
+
+    case = golden["g1_n16_cuzk_test"]
+    _, ws = util.oracle_msm_params(oracle, case["points"], case["scalars"], 16, 256, want_windows=True)
+    out = sharded_msm(lambda b, c: b"".join(util.partial_record_from_window_sum(R.decode_result(ws[96 * w : 96 * w + 96])) for w in range(b, b + c)), 0, 1)
+    assert out == case["expected"]

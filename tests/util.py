@@ -1,0 +1,123 @@
+"""Shared helpers for the tests (TEST INFRASTRUCTURE): oracle loading, golden loading,
+device-format encoders."""
+import ctypes
+import json
+import os
+import subprocess
+
+import pyref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libmsm_oracle.so")
+
+LB = 29
+LMASK = (1 << LB) - 1
+R29 = 1 << (LB * 13)  # device Montgomery radix for Fp
+
+
+def load_oracle():
+    """ctypes handle of the C oracle; built on demand (gcc) when the .so is missing or stale."""
+    src = [os.path.join(ROOT, "oracle", f) for f in ("msm_oracle.c", "ed_oracle.c", "Makefile")]
+    stale = not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in src if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(ORACLE_SO)
+    lib.oracle_g1_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.oracle_g1_msm_naive.argtypes = lib.oracle_g1_msm.argtypes
+    lib.oracle_g1_msm_params.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.oracle_g1_smvp_window.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    lib.oracle_decompose_scalars_signed.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p]
+    lib.oracle_cpu_transpose.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.oracle_cpu_transpose.restype = None
+    lib.oracle_g1_horner.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    lib.oracle_g1_scalar_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p]
+    lib.oracle_g1_add_affine.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+    lib.oracle_g1_proj_to_affine.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    lib.oracle_g1_on_curve.argtypes = [ctypes.c_char_p]
+    lib.oracle_g1_gen_points_arith.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+    lib.oracle_g1_generator.argtypes = [ctypes.c_void_p]
+    lib.oracle_g1_generator.restype = None
+    lib.oracle_fp_ops.argtypes = [ctypes.c_char_p] * 2 + [ctypes.c_void_p] * 3
+    lib.oracle_fp_ops.restype = None
+    lib.oracle_fp_mont_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.oracle_fp_mont_constants.restype = None
+    return lib
+
+
+def oracle_msm(lib, points: bytes, scalars: bytes, fn="oracle_g1_msm") -> bytes:
+    n = len(scalars) // 32
+    out = ctypes.create_string_buffer(96)
+    rc = getattr(lib, fn)(points, scalars, n, ctypes.addressof(out))
+    assert rc == 0, rc
+    return out.raw
+
+
+def oracle_msm_params(lib, points, scalars, c, T, want_windows=False):
+    n = len(scalars) // 32
+    W = (256 + c - 1) // c
+    out = ctypes.create_string_buffer(96)
+    ws = ctypes.create_string_buffer(96 * W) if want_windows else None
+    rc = lib.oracle_g1_msm_params(points, scalars, n, c, T, ctypes.addressof(out), ctypes.addressof(ws) if ws else None)
+    assert rc == 0, rc
+    return (out.raw, ws.raw) if want_windows else out.raw
+
+
+def oracle_gen_points(lib, n, a0, delta) -> bytes:
+    out = ctypes.create_string_buffer(96 * n)
+    rc = lib.oracle_g1_gen_points_arith(n, int(a0).to_bytes(32, "little"), int(delta).to_bytes(32, "little"), ctypes.addressof(out))
+    assert rc == 0, rc
+    return out.raw
+
+
+def load_golden():
+    with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
+        manifest = json.load(f)
+    cases = {}
+    for name, meta in manifest.items():
+        n = meta["n"]
+        with open(os.path.join(GOLDEN_DIR, name + ".bin"), "rb") as f:
+            blob = f.read()
+        assert len(blob) == 128 * n + 96
+        cases[name] = {"n": n, "points": blob[: 96 * n], "scalars": blob[96 * n : 128 * n], "expected": blob[128 * n :]}
+    return cases
+
+
+# ---- device formats ----
+def to_limbs29_mont(v: int):
+    """canonical residue -> 13 x 29-bit limbs of v * 2^377 mod p (csrc/field29.hpp format)."""
+    m = (v * R29) % R.P
+    return [(m >> (LB * i)) & LMASK for i in range(13)]
+
+
+def from_limbs29_mont(limbs) -> int:
+    m = sum(int(x) << (LB * i) for i, x in enumerate(limbs))
+    return (m * pow(R29, -1, R.P)) % R.P
+
+
+def xyzz_words_from_affine(pt):
+    """Affine point (or None) -> 52 device words X, Y, ZZ, ZZZ with ZZ = ZZZ = 1."""
+    if pt is None:
+        return to_limbs29_mont(0) + to_limbs29_mont(1) + [0] * 26
+    return to_limbs29_mont(pt[0]) + to_limbs29_mont(pt[1]) + to_limbs29_mont(1) + to_limbs29_mont(1)
+
+
+def affine_from_xyzz_words(words):
+    """52 device words -> affine point via Python ints (None for the identity)."""
+    X = from_limbs29_mont(words[0:13])
+    Y = from_limbs29_mont(words[13:26])
+    ZZ = from_limbs29_mont(words[26:39])
+    ZZZ = from_limbs29_mont(words[39:52])
+    if ZZ == 0:
+        return None
+    assert pow(ZZ, 3, R.P) == pow(ZZZ, 2, R.P), "XYZZ invariant ZZ^3 = ZZZ^2 violated"
+    return (X * pow(ZZ, -1, R.P) % R.P, Y * pow(ZZZ, -1, R.P) % R.P)
+
+
+def partial_record_from_window_sum(pt) -> bytes:
+    """A window partial record (include/msm377.h) whose point 0 is the window sum and whose 15
+    bit-plane points are the identity."""
+    import struct
+
+    words = xyzz_words_from_affine(pt) + (to_limbs29_mont(0) + to_limbs29_mont(1) + [0] * 26) * 15
+    return struct.pack("<%dI" % len(words), *words)

@@ -16,116 +16,132 @@
 
 namespace msm377 {
 
-struct G1Affine {
-  Fp::El x, y;  // Montgomery form; never the identity (the wire format has no encoding for it)
+// F is a field policy: Fp (29-bit limbs, device + host) or Fp64 (64-bit words, host tail).
+template <class F>
+struct G1T {
+  using El = typename F::El;
+
+  struct Affine {
+    El x, y;  // Montgomery form; never the identity (the wire format has no encoding for it)
+  };
+  struct XYZZ {
+    El x, y, zz, zzz;
+  };
+
+  static MSM_HD XYZZ identity() {
+    XYZZ r;
+    r.x = F::zero();
+    r.y = F::one();
+    r.zz = F::zero();
+    r.zzz = F::zero();
+    return r;
+  }
+  static MSM_HD bool is_identity(const XYZZ& p) { return F::is_zero(p.zz); }
+
+  static MSM_HD XYZZ from_affine(const Affine& p) {
+    XYZZ r;
+    r.x = p.x;
+    r.y = p.y;
+    r.zz = F::one();
+    r.zzz = F::one();
+    return r;
+  }
+
+  static MSM_HD XYZZ neg(const XYZZ& p) {
+    XYZZ r = p;
+    r.y = F::neg(p.y);
+    return r;
+  }
+
+  // EFD dbl-2008-s-1 with a = 0: 6M + 3S.  Y = 0 (a 2-torsion point) yields ZZ3 = 0.
+  static MSM_HD XYZZ dbl(const XYZZ& p) {
+    if (is_identity(p)) return p;
+    El u = F::dbl(p.y);
+    El v = F::sqr(u);
+    El w = F::mul(u, v);
+    El s = F::mul(p.x, v);
+    El xx = F::sqr(p.x);
+    El m = F::add(F::dbl(xx), xx);
+    XYZZ r;
+    r.x = F::sub(F::sqr(m), F::dbl(s));
+    r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+    r.zz = F::mul(v, p.zz);
+    r.zzz = F::mul(w, p.zzz);
+    return r;
+  }
+
+  // 2*(affine point): EFD mdbl-2008-s-1.
+  static MSM_HD XYZZ dbl_affine(const Affine& p) {
+    El u = F::dbl(p.y);
+    El v = F::sqr(u);
+    El w = F::mul(u, v);
+    El s = F::mul(p.x, v);
+    El xx = F::sqr(p.x);
+    El m = F::add(F::dbl(xx), xx);
+    XYZZ r;
+    r.x = F::sub(F::sqr(m), F::dbl(s));
+    r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+    r.zz = v;
+    r.zzz = w;
+    return r;
+  }
+
+  // acc + q, q affine: EFD madd-2008-s (8M + 2S) plus the cases it does not cover.
+  static MSM_HD XYZZ madd(const XYZZ& a, const Affine& q) {
+    if (is_identity(a)) return from_affine(q);
+    El u2 = F::mul(q.x, a.zz);
+    El s2 = F::mul(q.y, a.zzz);
+    El p = F::sub(u2, a.x);
+    El r = F::sub(s2, a.y);
+    if (F::is_zero(p)) {
+      if (F::is_zero(r)) return dbl_affine(q);  // same point
+      return identity();                         // opposite points
+    }
+    El pp = F::sqr(p);
+    El ppp = F::mul(p, pp);
+    El qq = F::mul(a.x, pp);
+    XYZZ o;
+    o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(a.y, ppp));
+    o.zz = F::mul(a.zz, pp);
+    o.zzz = F::mul(a.zzz, ppp);
+    return o;
+  }
+
+  // General addition: EFD add-2008-s (12M + 2S) plus identity / equal / opposite inputs.
+  static MSM_HD XYZZ add(const XYZZ& a, const XYZZ& b) {
+    if (is_identity(a)) return b;
+    if (is_identity(b)) return a;
+    El u1 = F::mul(a.x, b.zz);
+    El u2 = F::mul(b.x, a.zz);
+    El s1 = F::mul(a.y, b.zzz);
+    El s2 = F::mul(b.y, a.zzz);
+    El p = F::sub(u2, u1);
+    El r = F::sub(s2, s1);
+    if (F::is_zero(p)) {
+      if (F::is_zero(r)) return dbl(a);
+      return identity();
+    }
+    El pp = F::sqr(p);
+    El ppp = F::mul(p, pp);
+    El qq = F::mul(u1, pp);
+    XYZZ o;
+    o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(s1, ppp));
+    o.zz = F::mul(F::mul(a.zz, b.zz), pp);
+    o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
+    return o;
+  }
 };
 
-struct G1XYZZ {
-  Fp::El x, y, zz, zzz;
-};
-
-MSM_HD G1XYZZ g1_identity() {
-  G1XYZZ r;
-  r.x = Fp::zero();
-  r.y = Fp::one();
-  r.zz = Fp::zero();
-  r.zzz = Fp::zero();
-  return r;
-}
-MSM_HD bool g1_is_identity(const G1XYZZ& p) { return Fp::is_zero(p.zz); }
-
-MSM_HD G1XYZZ g1_from_affine(const G1Affine& p) {
-  G1XYZZ r;
-  r.x = p.x;
-  r.y = p.y;
-  r.zz = Fp::one();
-  r.zzz = Fp::one();
-  return r;
-}
-
-MSM_HD G1XYZZ g1_neg(const G1XYZZ& p) {
-  G1XYZZ r = p;
-  r.y = Fp::neg(p.y);
-  return r;
-}
-
-// EFD dbl-2008-s-1 with a = 0: 6M + 3S.  Y = 0 (a 2-torsion point) yields ZZ3 = 0.
-MSM_HD G1XYZZ g1_dbl(const G1XYZZ& p) {
-  Fp::El u = Fp::dbl(p.y);
-  Fp::El v = Fp::sqr(u);
-  Fp::El w = Fp::mul(u, v);
-  Fp::El s = Fp::mul(p.x, v);
-  Fp::El xx = Fp::sqr(p.x);
-  Fp::El m = Fp::add(Fp::dbl(xx), xx);
-  G1XYZZ r;
-  r.x = Fp::sub(Fp::sqr(m), Fp::dbl(s));
-  r.y = Fp::sub(Fp::mul(m, Fp::sub(s, r.x)), Fp::mul(w, p.y));
-  r.zz = Fp::mul(v, p.zz);
-  r.zzz = Fp::mul(w, p.zzz);
-  return r;
-}
-
-// 2*(affine point): EFD mdbl-2008-s-1.
-MSM_HD G1XYZZ g1_dbl_affine(const G1Affine& p) {
-  Fp::El u = Fp::dbl(p.y);
-  Fp::El v = Fp::sqr(u);
-  Fp::El w = Fp::mul(u, v);
-  Fp::El s = Fp::mul(p.x, v);
-  Fp::El xx = Fp::sqr(p.x);
-  Fp::El m = Fp::add(Fp::dbl(xx), xx);
-  G1XYZZ r;
-  r.x = Fp::sub(Fp::sqr(m), Fp::dbl(s));
-  r.y = Fp::sub(Fp::mul(m, Fp::sub(s, r.x)), Fp::mul(w, p.y));
-  r.zz = v;
-  r.zzz = w;
-  return r;
-}
-
-// acc + q, q affine: EFD madd-2008-s (8M + 2S) plus the cases it does not cover.
-MSM_HD G1XYZZ g1_madd(const G1XYZZ& a, const G1Affine& q) {
-  if (g1_is_identity(a)) return g1_from_affine(q);
-  Fp::El u2 = Fp::mul(q.x, a.zz);
-  Fp::El s2 = Fp::mul(q.y, a.zzz);
-  Fp::El p = Fp::sub(u2, a.x);
-  Fp::El r = Fp::sub(s2, a.y);
-  if (Fp::is_zero(p)) {
-    if (Fp::is_zero(r)) return g1_dbl_affine(q);  // same point
-    return g1_identity();                          // opposite points
-  }
-  Fp::El pp = Fp::sqr(p);
-  Fp::El ppp = Fp::mul(p, pp);
-  Fp::El qq = Fp::mul(a.x, pp);
-  G1XYZZ o;
-  o.x = Fp::sub(Fp::sub(Fp::sqr(r), ppp), Fp::dbl(qq));
-  o.y = Fp::sub(Fp::mul(r, Fp::sub(qq, o.x)), Fp::mul(a.y, ppp));
-  o.zz = Fp::mul(a.zz, pp);
-  o.zzz = Fp::mul(a.zzz, ppp);
-  return o;
-}
-
-// General addition: EFD add-2008-s (12M + 2S) plus identity / equal / opposite inputs.
-MSM_HD G1XYZZ g1_add(const G1XYZZ& a, const G1XYZZ& b) {
-  if (g1_is_identity(a)) return b;
-  if (g1_is_identity(b)) return a;
-  Fp::El u1 = Fp::mul(a.x, b.zz);
-  Fp::El u2 = Fp::mul(b.x, a.zz);
-  Fp::El s1 = Fp::mul(a.y, b.zzz);
-  Fp::El s2 = Fp::mul(b.y, a.zzz);
-  Fp::El p = Fp::sub(u2, u1);
-  Fp::El r = Fp::sub(s2, s1);
-  if (Fp::is_zero(p)) {
-    if (Fp::is_zero(r)) return g1_dbl(a);
-    return g1_identity();
-  }
-  Fp::El pp = Fp::sqr(p);
-  Fp::El ppp = Fp::mul(p, pp);
-  Fp::El qq = Fp::mul(u1, pp);
-  G1XYZZ o;
-  o.x = Fp::sub(Fp::sub(Fp::sqr(r), ppp), Fp::dbl(qq));
-  o.y = Fp::sub(Fp::mul(r, Fp::sub(qq, o.x)), Fp::mul(s1, ppp));
-  o.zz = Fp::mul(Fp::mul(a.zz, b.zz), pp);
-  o.zzz = Fp::mul(Fp::mul(a.zzz, b.zzz), ppp);
-  return o;
-}
+using G1 = G1T<Fp>;
+using G1Affine = G1::Affine;
+using G1XYZZ = G1::XYZZ;
+MSM_HD G1XYZZ g1_identity() { return G1::identity(); }
+MSM_HD bool g1_is_identity(const G1XYZZ& p) { return G1::is_identity(p); }
+MSM_HD G1XYZZ g1_from_affine(const G1Affine& p) { return G1::from_affine(p); }
+MSM_HD G1XYZZ g1_dbl(const G1XYZZ& p) { return G1::dbl(p); }
+MSM_HD G1XYZZ g1_madd(const G1XYZZ& a, const G1Affine& q) { return G1::madd(a, q); }
+MSM_HD G1XYZZ g1_add(const G1XYZZ& a, const G1XYZZ& b) { return G1::add(a, b); }
 
 }  // namespace msm377

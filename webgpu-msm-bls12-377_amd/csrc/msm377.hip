@@ -1,0 +1,749 @@
+// msm377: BLS12-377 G1 multi-scalar multiplication for MI355X (gfx950), C ABI in
+// include/msm377.h.  One translation unit: device kernels, the stage sequencer and the
+// host tail.
+//
+// Pipeline (each stage names the reference code it replaces; paths relative to
+// /root/reference/src/submission/):
+//   k_convert_bases   wire x||y -> Montgomery records            wgsl/cuzk/convert_point_coords_and_decompose_scalars.template.wgsl:41-99 + barrett.template.wgsl:60-82
+//   k_decompose       scalars -> signed 16-bit digits            same file :100-141; model cuzk/utils.ts:66-109
+//   k_hist / k_chunk_prefix / k_scan_totals / k_scatter
+//                     per-window counting sort -> CSR            wgsl/cuzk/transpose_serial.wgsl:34-76 (16 serial threads there); model cuzk/transpose.ts:14-62
+//   k_accumulate      bucket sums (the dominant kernel)          wgsl/cuzk/smvp_bls12_377.template.wgsl:72-160
+//   k_tree_step       bucket reduction, log-depth bit planes     wgsl/cuzk/bpr.template.wgsl:69-173; models cuzk/bpr.ts:5-126
+//   host tail         Horner over windows + one inversion        submission.ts:290-321
+//
+// HBM layout (n points, W window slots, NB = 32768 buckets per window):
+//   bases    n x 128 B records: x[13] y[13] pad[6] u32 (29-bit limbs, Montgomery R = 2^377);
+//            one record = one 128-byte line, so a gather touches exactly one line
+//   digits   W x n u16, window-major: biased digit d + 2^15 (the reference's chunks[] as u32)
+//   row_ptr  W x 32770 u32: CSR offsets over keys |d| in 0..32768 (the reference keeps 65537
+//            signed rows; here +t and -t share row t and the sign rides in val_idx bit 31)
+//   val_idx  W x n u32: point index | sign << 31
+//   buckets  W x 52 x NB u32, limb-major ("SoA"): word j of bucket t at [(w*52+j)*NB + t-1],
+//            so thread-per-bucket loads/stores are fully coalesced
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+
+#include "../../include/msm377.h"
+#include "fp64_host.hpp"
+#include "g1_xyzz.hpp"
+
+using namespace msm377;
+
+namespace {
+
+constexpr uint32_t NB = 32768;     // buckets per window: |d| = 1..32768
+constexpr uint32_t NBIN = NB + 1;  // sort keys 0..32768 (key 0 = digit 0, never accumulated)
+constexpr uint32_t RP = NBIN + 1;  // row_ptr entries per window
+constexpr uint32_t REC_WORDS = 32; // one base record, 128 bytes
+constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
+constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) pairs: one 131 KB LDS histogram per CU
+constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
+
+// ------------------------------------------------------------------ device helpers ----
+
+__device__ __forceinline__ void load_words16(const uint32_t* __restrict__ p, uint32_t* w, int nvec) {
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int k = 0; k < nvec; k++) {
+    uint4 v = s[k];
+    w[4 * k + 0] = v.x;
+    w[4 * k + 1] = v.y;
+    w[4 * k + 2] = v.z;
+    w[4 * k + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ G1Affine load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
+  uint32_t w[28];
+  load_words16(bases + (size_t)idx * REC_WORDS, w, 7);
+  G1Affine p;
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    p.x.l[j] = w[j];
+    p.y.l[j] = w[13 + j];
+  }
+  return p;
+}
+
+__device__ __forceinline__ G1XYZZ load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
+  const uint32_t* p = b + (size_t)ws * PT_WORDS * NB + t;
+  G1XYZZ r;
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    r.x.l[j] = p[(size_t)j * NB];
+    r.y.l[j] = p[(size_t)(13 + j) * NB];
+    r.zz.l[j] = p[(size_t)(26 + j) * NB];
+    r.zzz.l[j] = p[(size_t)(39 + j) * NB];
+  }
+  return r;
+}
+__device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t ws, uint32_t t, const G1XYZZ& r) {
+  uint32_t* p = b + (size_t)ws * PT_WORDS * NB + t;
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    p[(size_t)j * NB] = r.x.l[j];
+    p[(size_t)(13 + j) * NB] = r.y.l[j];
+    p[(size_t)(26 + j) * NB] = r.zz.l[j];
+    p[(size_t)(39 + j) * NB] = r.zzz.l[j];
+  }
+}
+
+// ------------------------------------------------------------------------ kernels ----
+
+// One thread per point: 96-byte wire record -> 128-byte Montgomery record.
+__global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[24];
+  load_words16(raw + i * 24, w, 6);
+  Fp::El x = Fp::to_mont(Fp::from_words<12>(w));
+  Fp::El y = Fp::to_mont(Fp::from_words<12>(w + 12));
+  uint32_t o[32];
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    o[j] = x.l[j];
+    o[13 + j] = y.l[j];
+  }
+#pragma unroll
+  for (int j = 26; j < 32; j++) o[j] = 0;
+  uint4* dst = reinterpret_cast<uint4*>(bases + i * REC_WORDS);
+#pragma unroll
+  for (int k = 0; k < 8; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// One thread per scalar: 16 signed digits d_w in [-2^15, 2^15), stored biased (d + 2^15).
+// Only windows [wb, wb + wc) are written (window sharding); the carry chain always runs over
+// all 16.  A final carry (scalar >= 2^255 - 2^239) sets *err, as cuzk/utils.ts:95-98 throws.
+__global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n,
+                                                   uint32_t wb, uint32_t wc, int* __restrict__ err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words16(scalars + i * 8, w, 2);
+  uint32_t carry = 0;
+#pragma unroll
+  for (uint32_t win = 0; win < 16; win++) {
+    uint32_t limb = (w[win >> 1] >> (16 * (win & 1))) & 0xffffu;
+    uint32_t v = limb + carry;
+    carry = v >= 32768u ? 1u : 0u;
+    if (win >= wb && win < wb + wc) digits[(size_t)(win - wb) * n + i] = (uint16_t)((v + 32768u) & 0xffffu);
+  }
+  if (carry) atomicOr(err, 1);
+}
+
+__device__ __forceinline__ void digit_key(uint32_t biased, uint32_t& key, uint32_t& sign) {
+  int d = (int)biased - 32768;
+  sign = d < 0 ? 1u : 0u;
+  key = (uint32_t)(d < 0 ? -d : d);
+}
+
+// Block (chunk c, window slot ws): histogram of the chunk's keys in LDS (131 KB), written
+// out as hist_chunk[ws][c][key].
+__global__ void __launch_bounds__(1024) k_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ hist_chunk, uint64_t n,
+                                               uint32_t chunks, uint64_t per_chunk) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  for (uint32_t k = tid; k < NBIN; k += 1024) lds[k] = 0;
+  __syncthreads();
+  const uint64_t beg = (uint64_t)c * per_chunk;
+  const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
+  const uint16_t* dg = digits + (size_t)ws * n;
+  for (uint64_t i = beg + tid; i < end; i += 1024) {
+    uint32_t key, sign;
+    digit_key(dg[i], key, sign);
+    atomicAdd(&lds[key], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = hist_chunk + ((size_t)ws * chunks + c) * NBIN;
+  for (uint32_t k = tid; k < NBIN; k += 1024) out[k] = lds[k];
+}
+
+// Thread per (key, window slot): exclusive prefix over the chunks, total into tot[].
+__global__ void __launch_bounds__(256) k_chunk_prefix(uint32_t* __restrict__ hist_chunk, uint32_t* __restrict__ tot, uint32_t chunks) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x, ws = blockIdx.y;
+  if (k >= NBIN) return;
+  uint32_t run = 0;
+  uint32_t* h = hist_chunk + (size_t)ws * chunks * NBIN + k;
+  for (uint32_t c = 0; c < chunks; c++) {
+    uint32_t v = h[(size_t)c * NBIN];
+    h[(size_t)c * NBIN] = run;
+    run += v;
+  }
+  tot[(size_t)ws * NBIN + k] = run;
+}
+
+// Block per window slot: row_ptr = exclusive scan of the 32769 key totals.
+__global__ void __launch_bounds__(1024) k_scan_totals(const uint32_t* __restrict__ tot, uint32_t* __restrict__ row_ptr) {
+  __shared__ uint32_t part[1024];
+  const uint32_t ws = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* t = tot + (size_t)ws * NBIN;
+  uint32_t* rp = row_ptr + (size_t)ws * RP;
+  constexpr uint32_t PER = (NBIN + 1023) / 1024;  // 33
+  const uint32_t base = tid * PER;
+  uint32_t s = 0;
+  for (uint32_t j = 0; j < PER; j++) {
+    uint32_t k = base + j;
+    if (k < NBIN) s += t[k];
+  }
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
+  for (uint32_t j = 0; j < PER; j++) {
+    uint32_t k = base + j;
+    if (k < NBIN) {
+      rp[k] = run;
+      run += t[k];
+    }
+  }
+  if (tid == 1023) rp[NBIN] = part[1023];
+}
+
+// Block (chunk, window slot): cursor[key] = row_ptr[key] + (keys of earlier chunks) in LDS,
+// then every element takes its slot with one LDS atomic.  Order inside a bucket is free
+// (group addition commutes; the reference's transpose is stable only because it is serial).
+__global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ hist_chunk,
+                                                  const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
+                                                  uint32_t chunks, uint64_t per_chunk) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t* h = hist_chunk + ((size_t)ws * chunks + c) * NBIN;
+  const uint32_t* rp = row_ptr + (size_t)ws * RP;
+  for (uint32_t k = tid; k < NBIN; k += 1024) lds[k] = rp[k] + h[k];
+  __syncthreads();
+  const uint64_t beg = (uint64_t)c * per_chunk;
+  const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
+  const uint16_t* dg = digits + (size_t)ws * n;
+  uint32_t* vi = val_idx + (size_t)ws * n;
+  for (uint64_t i = beg + tid; i < end; i += 1024) {
+    uint32_t key, sign;
+    digit_key(dg[i], key, sign);
+    uint32_t pos = atomicAdd(&lds[key], 1u);
+    vi[pos] = (uint32_t)i | (sign << 31);
+  }
+}
+
+// Bucket accumulation: one thread per (window slot, bucket t = 1..32768).  Walks the CSR row
+// of key t and adds +P for digit +t, -P for digit -t (the reference's thread handles rows
+// t+h and h-t and negates the second sum, smvp_bls12_377.template.wgsl:96-133; its bucket 0 =
+// digit -2^15 is bucket 32768 here).  The next record is requested before the current mixed
+// addition so the gather latency hides under ~10 field multiplications.
+__global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
+                                                       const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t ws = g / NB, t = g % NB;  // bucket index t <-> key t + 1
+  const uint32_t* rp = row_ptr + (size_t)ws * RP;
+  const uint32_t* vi = val_idx + (size_t)ws * n;
+  uint32_t k = rp[t + 1];
+  const uint32_t end = rp[t + 2];
+  G1XYZZ acc = g1_identity();
+  if (k < end) {
+    uint32_t e = vi[k];
+    G1Affine p = load_base(bases, e & 0x7fffffffu);
+    while (true) {
+      const uint32_t e_cur = e;
+      G1Affine cur = p;
+      k++;
+      const bool more = k < end;
+      if (more) {
+        e = vi[k];
+        p = load_base(bases, e & 0x7fffffffu);
+      }
+      cur.y = Fp::cneg(cur.y, (e_cur >> 31) != 0);
+      acc = g1_madd(acc, cur);
+      if (!more) break;
+    }
+  }
+  store_bucket(buckets, ws, t, acc);
+}
+
+// Bucket reduction, level r of 15.  Per window the buckets B[0..NB) (B[i] has weight i+1) are
+// reduced in place to  B[0] = sum of all buckets  and  B[2^l] = sum of buckets whose index has
+// bit l set  (l = 0..14), so that  sum_i (i+1) B[i] = B[0] + sum_l 2^l B[2^l].
+// Level r performs, for every offset o in {0, 2^0, .., 2^(r-1)} and k < NB/2^(r+1):
+//     B[o + k 2^(r+1)] += B[o + k 2^(r+1) + 2^r]
+// (o = 0: pairwise sums of the running blocks; o = 2^l: pairwise tree over level l's odd
+// blocks).  All (x, y) pairs of one level are disjoint.  Total work 2 NB additions per window
+// -- the same as the reference's running sum (bpr.template.wgsl:99-107) -- at depth 15
+// instead of 2 * 128 + a 15-bit double-and-add per thread.
+__global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t ws = blockIdx.y;
+  if (g >= ops_per_window) return;
+  const uint32_t per_off = NB >> (r + 1);
+  const uint32_t oi = g / per_off, kk = g % per_off;
+  const uint32_t o = oi == 0 ? 0u : (1u << (oi - 1));
+  const uint32_t x = o + (kk << (r + 1));
+  const uint32_t y = x + (1u << r);
+  G1XYZZ a = load_bucket(buckets, ws, x);
+  G1XYZZ b = load_bucket(buckets, ws, y);
+  store_bucket(buckets, ws, x, g1_add(a, b));
+}
+
+// Pack the 16 partial points of every window slot: point 0 = B[0], point 1 + l = B[2^l].
+__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out) {
+  const uint32_t ws = blockIdx.x, pt = blockIdx.y, j = threadIdx.x;
+  if (j >= PT_WORDS) return;
+  const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
+  out[((size_t)ws * MSM377_G1_PARTIAL_POINTS + pt) * PT_WORDS + j] = buckets[((size_t)ws * PT_WORDS + j) * NB + x];
+}
+
+// Synthetic bases: P_i = [a_i]G with a_i the (i+1)-th SplitMix64(seed) output, wire format.
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256, 2) k_generate_bases(uint64_t seed, uint64_t n, uint32_t* __restrict__ out_raw) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t a = splitmix64_at(seed, i);
+  if (a == 0) a = 1;
+  G1Affine gen;
+  gen.x = Fp::from_const(G1Consts::GEN_X);
+  gen.y = Fp::from_const(G1Consts::GEN_Y);
+  G1XYZZ acc = g1_identity();
+#pragma unroll 1
+  for (int bit = 63; bit >= 0; bit--) {
+    acc = g1_dbl(acc);
+    if ((a >> bit) & 1) acc = g1_madd(acc, gen);
+  }
+  // affine: x = X * (ZZ/ZZZ)^2, y = Y / ZZZ
+  Fp::El i3 = Fp::one();
+#pragma unroll 1
+  for (int b = G1Consts::PM2_NW * 32 - 1; b >= 0; b--) {
+    i3 = Fp::sqr(i3);
+    if ((G1Consts::PM2_W[b >> 5] >> (b & 31)) & 1u) i3 = Fp::mul(i3, acc.zzz);
+  }
+  Fp::El tt = Fp::mul(i3, acc.zz);
+  Fp::El x = Fp::from_mont(Fp::mul(acc.x, Fp::sqr(tt)));
+  Fp::El y = Fp::from_mont(Fp::mul(acc.y, i3));
+  uint32_t w[24];
+  Fp::to_words<12>(x, w);
+  Fp::to_words<12>(y, w + 12);
+  uint4* dst = reinterpret_cast<uint4*>(out_raw + i * 24);
+#pragma unroll
+  for (int k = 0; k < 6; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------- context ----
+
+struct msm377_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t cap = 0;
+  std::string err;
+  // device buffers
+  uint32_t* d_raw_points = nullptr;   // cap x 24 words (host-buffer API staging)
+  uint32_t* d_raw_scalars = nullptr;  // cap x 8 words
+  uint32_t* d_bases = nullptr;        // cap x 32 words
+  uint16_t* d_digits = nullptr;       // 16 x cap
+  uint32_t* d_hist_chunk = nullptr;   // MAX_SORT_BLOCKS x NBIN
+  uint32_t* d_tot = nullptr;          // 16 x NBIN
+  uint32_t* d_row_ptr = nullptr;      // 16 x RP
+  uint32_t* d_val_idx = nullptr;      // 16 x cap
+  uint32_t* d_buckets = nullptr;      // 16 x 52 x NB
+  uint32_t* d_buckets_snap = nullptr; // stage capture only
+  uint32_t* d_partials = nullptr;     // 16 x 16 x 52
+  int* d_err = nullptr;
+  // pinned host
+  uint32_t* h_partials = nullptr;
+  int* h_err = nullptr;
+  // state
+  uint64_t bases_n = 0;  // resident base count (fixed-base mode)
+  uint64_t last_n = 0;
+  uint32_t last_wc = 0;
+  bool capture = false;
+  bool timing = false;
+  hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
+  double stage_ms[MSM377_NUM_STAGES] = {};
+};
+
+namespace {
+
+bool hip_ok(msm377_ctx* ctx, hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  if (ctx) ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+#define HIP_TRY(ctx, call)                            \
+  do {                                                \
+    if (!hip_ok((ctx), (call), #call)) return MSM377_EHIP; \
+  } while (0)
+
+void identity_wire(uint8_t out[96]) {
+  memset(out, 0, 96);
+  out[48] = 1;
+}
+
+struct StageTimer {
+  msm377_ctx* c;
+  int s;
+  StageTimer(msm377_ctx* ctx, int stage) : c(ctx), s(stage) {
+    if (c->timing) (void)hipEventRecord(c->ev[s][0], c->stream);
+  }
+  ~StageTimer() {
+    if (c->timing) (void)hipEventRecord(c->ev[s][1], c->stream);
+  }
+};
+
+int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
+  StageTimer t(ctx, MSM377_STAGE_CONVERT);
+  if (n == 0) return MSM377_OK;
+  hipLaunchKernelGGL(k_convert_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, ctx->d_bases, n);
+  HIP_TRY(ctx, hipGetLastError());
+  return MSM377_OK;
+}
+
+// Stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases; leaves the
+// partial records in ctx->h_partials (wc x 16 x 52 words) and synchronises the stream.
+int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc) {
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), st));
+  {
+    StageTimer t(ctx, MSM377_STAGE_DECOMPOSE);
+    hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, ctx->d_err);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  {
+    StageTimer t(ctx, MSM377_STAGE_SORT);
+    uint32_t chunks = MAX_SORT_BLOCKS / wc;
+    const uint64_t want = (n + 4095) / 4096;  // at least ~4096 elements per block
+    if (chunks > want) chunks = (uint32_t)(want ? want : 1);
+    const uint64_t per_chunk = (n + chunks - 1) / chunks;
+    const size_t lds_bytes = NBIN * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_hist, dim3(chunks, wc), dim3(1024), lds_bytes, st, ctx->d_digits, ctx->d_hist_chunk, n, chunks, per_chunk);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_chunk_prefix, dim3((NBIN + 255) / 256, wc), dim3(256), 0, st, ctx->d_hist_chunk, ctx->d_tot, chunks);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_totals, dim3(wc), dim3(1024), 0, st, ctx->d_tot, ctx->d_row_ptr);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_scatter, dim3(chunks, wc), dim3(1024), lds_bytes, st, ctx->d_digits, ctx->d_hist_chunk, ctx->d_row_ptr,
+                       ctx->d_val_idx, n, chunks, per_chunk);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  {
+    StageTimer t(ctx, MSM377_STAGE_ACCUMULATE);
+    hipLaunchKernelGGL(k_accumulate, dim3(wc * (NB / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx, ctx->d_bases, ctx->d_buckets, n);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->capture) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, ctx->d_buckets, (size_t)wc * PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
+  }
+  {
+    StageTimer t(ctx, MSM377_STAGE_REDUCE);
+    for (uint32_t r = 0; r < TREE_LEVELS; r++) {
+      const uint32_t ops = (r + 1) * (NB >> (r + 1));
+      hipLaunchKernelGGL(k_tree_step, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_gather_partials, dim3(wc, MSM377_G1_PARTIAL_POINTS), dim3(64), 0, st, ctx->d_buckets, ctx->d_partials);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials, (size_t)wc * MSM377_G1_WINDOW_PARTIAL_BYTES, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->last_n = n;
+  ctx->last_wc = wc;
+  if (ctx->timing) {
+    for (int s = 0; s < MSM377_STAGE_TAIL; s++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->ev[s][0], ctx->ev[s][1]) == hipSuccess) ctx->stage_ms[s] = ms;
+    }
+  }
+  if (*ctx->h_err) {
+    ctx->err = "a scalar overflows the signed 16-bit window recode (final carry)";
+    return MSM377_ESCALAR;
+  }
+  return MSM377_OK;
+}
+
+int check_args(msm377_ctx* ctx, const void* a, const void* b, uint64_t n, bool need_a) {
+  if (!ctx) return MSM377_EINVAL;
+  ctx->err.clear();
+  if (n > ctx->cap) {
+    ctx->err = "n exceeds the context capacity";
+    return MSM377_EINVAL;
+  }
+  if (n && ((need_a && !a) || !b)) {
+    ctx->err = "null input pointer";
+    return MSM377_EINVAL;
+  }
+  if (((uintptr_t)a & 15) || ((uintptr_t)b & 15)) {
+    ctx->err = "device input pointers must be 16-byte aligned";
+    return MSM377_EINVAL;
+  }
+  return MSM377_OK;
+}
+
+int finish_full(msm377_ctx* ctx, uint8_t out_xy[96]) {
+  auto t0 = std::chrono::steady_clock::now();
+  g1h_combine(ctx->h_partials, out_xy);
+  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MSM377_OK;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------- C ABI ----
+
+extern "C" {
+
+const char* msm377_version(void) { return "msm377 0.1 gfx950"; }
+
+const char* msm377_strerror(int code) {
+  switch (code) {
+    case MSM377_OK: return "ok";
+    case MSM377_EINVAL: return "invalid argument";
+    case MSM377_EHIP: return "HIP runtime error";
+    case MSM377_ESCALAR: return "scalar out of range for the signed window recode";
+    case MSM377_ENOMEM: return "out of memory";
+    case MSM377_ESTATE: return "call sequence error";
+    default: return "unknown error";
+  }
+}
+
+int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
+  if (!out || max_points == 0 || max_points > (1ull << 30)) return MSM377_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return MSM377_EHIP;
+  msm377_ctx* ctx = new (std::nothrow) msm377_ctx();
+  if (!ctx) return MSM377_ENOMEM;
+  ctx->device = device;
+  ctx->cap = max_points;
+  const uint64_t cap = max_points;
+  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+  auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
+  dalloc((void**)&ctx->d_raw_points, cap * 96);
+  dalloc((void**)&ctx->d_raw_scalars, cap * 32);
+  dalloc((void**)&ctx->d_bases, cap * REC_WORDS * 4);
+  dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
+  dalloc((void**)&ctx->d_hist_chunk, (size_t)MAX_SORT_BLOCKS * NBIN * 4);
+  dalloc((void**)&ctx->d_tot, (size_t)MSM377_NUM_WINDOWS * NBIN * 4);
+  dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
+  dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
+  dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
+  dalloc((void**)&ctx->d_partials, (size_t)MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
+  dalloc((void**)&ctx->d_err, sizeof(int));
+  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_err, sizeof(int)) == hipSuccess;
+  for (int s = 0; ok && s < MSM377_NUM_STAGES; s++)
+    for (int k = 0; k < 2; k++) ok = ok && hipEventCreate(&ctx->ev[s][k]) == hipSuccess;
+  const size_t lds_bytes = NBIN * sizeof(uint32_t);
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  if (!ok) {
+    msm377_ctx_destroy(ctx);
+    return MSM377_ENOMEM;
+  }
+  *out = ctx;
+  return MSM377_OK;
+}
+
+void msm377_ctx_destroy(msm377_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_hist_chunk, ctx->d_tot,
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_err};
+  for (void* p : bufs)
+    if (p) (void)hipFree(p);
+  if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  for (int s = 0; s < MSM377_NUM_STAGES; s++)
+    for (int k = 0; k < 2; k++)
+      if (ctx->ev[s][k]) (void)hipEventDestroy(ctx->ev[s][k]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* msm377_last_error(const msm377_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[96]) {
+  if (!out_xy) return MSM377_EINVAL;
+  int rc = check_args(ctx, d_points, d_scalars, n, true);
+  if (rc) return rc;
+  if (n == 0) {
+    identity_wire(out_xy);
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->bases_n = 0;
+  rc = convert_bases(ctx, (const uint32_t*)d_points, n);
+  if (rc) return rc;
+  rc = run_windows(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  if (rc) return rc;
+  return finish_full(ctx, out_xy);
+}
+
+int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
+  if (!ctx || !out_xy) return MSM377_EINVAL;
+  ctx->err.clear();
+  if (n > ctx->cap || (n && (!points || !scalars))) {
+    ctx->err = "bad arguments";
+    return MSM377_EINVAL;
+  }
+  if (n == 0) {
+    identity_wire(out_xy);
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_scalars, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return msm377_g1_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
+}
+
+int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
+  int rc = check_args(ctx, d_points, d_points, n, true);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = convert_bases(ctx, (const uint32_t*)d_points, n);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->bases_n = n;
+  return MSM377_OK;
+}
+
+int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n) {
+  if (!ctx || n > ctx->cap || (n && !points)) return MSM377_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  return msm377_g1_set_bases_device(ctx, ctx->d_raw_points, n);
+}
+
+int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint8_t out_xy[96]) {
+  if (!out_xy) return MSM377_EINVAL;
+  int rc = check_args(ctx, nullptr, d_scalars, n, false);
+  if (rc) return rc;
+  if (n > ctx->bases_n) {
+    ctx->err = "fixed-base MSM needs msm377_g1_set_bases with at least n points first";
+    return MSM377_ESTATE;
+  }
+  if (n == 0) {
+    identity_wire(out_xy);
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->timing) {  // no conversion in this mode
+    (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream);
+    (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream);
+  }
+  rc = run_windows(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  if (rc) return rc;
+  return finish_full(ctx, out_xy);
+}
+
+int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
+  if (!ctx || !out_xy || n > ctx->cap || (n && !scalars)) return MSM377_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_scalars, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return msm377_g1_msm_fixed_base_device(ctx, ctx->d_raw_scalars, n, out_xy);
+}
+
+int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin,
+                                     uint32_t win_count, uint8_t* partials_out) {
+  if (!partials_out) return MSM377_EINVAL;
+  int rc = check_args(ctx, d_points, d_scalars, n, true);
+  if (rc) return rc;
+  if (win_count == 0 || win_begin >= MSM377_NUM_WINDOWS || win_count > MSM377_NUM_WINDOWS - win_begin) {
+    ctx->err = "window range outside 0..16";
+    return MSM377_EINVAL;
+  }
+  if (n == 0) {  // identity partials: ZZ = 0 everywhere
+    memset(partials_out, 0, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->bases_n = 0;
+  rc = convert_bases(ctx, (const uint32_t*)d_points, n);
+  if (rc) return rc;
+  rc = run_windows(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count);
+  if (rc) return rc;
+  memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+  return MSM377_OK;
+}
+
+int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]) {
+  if (!partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
+  g1h_combine(reinterpret_cast<const uint32_t*>(partials), out_xy);
+  return MSM377_OK;
+}
+
+int msm377_g1_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out) {
+  if (!ctx || (n && !d_points_out) || ((uintptr_t)d_points_out & 15)) return MSM377_EINVAL;
+  if (n == 0) return MSM377_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_generate_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, n, (uint32_t*)d_points_out);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM377_OK;
+}
+
+int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled) {
+  if (!ctx) return MSM377_EINVAL;
+  if (enabled && !ctx->d_buckets_snap) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc((void**)&ctx->d_buckets_snap, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4) != hipSuccess) return MSM377_ENOMEM;
+  }
+  ctx->capture = enabled != 0;
+  return MSM377_OK;
+}
+
+int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint32_t* row_ptr, uint32_t* val_idx, uint32_t* buckets) {
+  if (!ctx) return MSM377_EINVAL;
+  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc) {
+    ctx->err = "no captured stage data for that window slot";
+    return MSM377_ESTATE;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t n = ctx->last_n;
+  if (digits) HIP_TRY(ctx, hipMemcpy(digits, ctx->d_digits + (size_t)slot * n, n * 2, hipMemcpyDeviceToHost));
+  if (row_ptr) HIP_TRY(ctx, hipMemcpy(row_ptr, ctx->d_row_ptr + (size_t)slot * RP, RP * 4, hipMemcpyDeviceToHost));
+  if (val_idx) HIP_TRY(ctx, hipMemcpy(val_idx, ctx->d_val_idx + (size_t)slot * n, n * 4, hipMemcpyDeviceToHost));
+  if (buckets) {
+    uint32_t* tmp = (uint32_t*)malloc((size_t)PT_WORDS * NB * 4);
+    if (!tmp) return MSM377_ENOMEM;
+    hipError_t e = hipMemcpy(tmp, ctx->d_buckets_snap + (size_t)slot * PT_WORDS * NB, (size_t)PT_WORDS * NB * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      for (uint32_t t = 0; t < NB; t++)
+        for (uint32_t j = 0; j < PT_WORDS; j++) buckets[(size_t)t * PT_WORDS + j] = tmp[(size_t)j * NB + t];
+    free(tmp);
+    HIP_TRY(ctx, e);
+  }
+  return MSM377_OK;
+}
+
+int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]) {
+  if (!xyzz || !out_xy) return MSM377_EINVAL;
+  g1h_to_wire(g1h_from_device_words(xyzz), out_xy);
+  return MSM377_OK;
+}
+
+int msm377_ctx_set_timing(msm377_ctx* ctx, int enabled) {
+  if (!ctx) return MSM377_EINVAL;
+  ctx->timing = enabled != 0;
+  return MSM377_OK;
+}
+
+int msm377_ctx_get_stage_ms(msm377_ctx* ctx, double* ms_out) {
+  if (!ctx || !ms_out) return MSM377_EINVAL;
+  for (int s = 0; s < MSM377_NUM_STAGES; s++) ms_out[s] = ctx->stage_ms[s];
+  return MSM377_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+"""ctypes binding of the C ABI in include/msm377.h (csrc/libmsm377.so).
+
+Replaces the reference's device runtime wrappers (src/submission/implementation/cuzk/gpu.ts:2-170:
+get_device, create_and_write_sb, create_compute_pipeline, execute_pipeline, read_from_gpu):
+a context owns the HIP stream and every HBM buffer, and one call runs the whole pipeline.
+No CPU fallback exists: a missing library raises at import-use time, a missing GPU raises
+MsmError(MSM377_EHIP) at context creation.
+"""
+import ctypes
+import os
+from typing import List, Optional, Sequence, Tuple
+
+NUM_WINDOWS = 16
+WINDOW_BITS = 16
+PARTIAL_POINTS = 16
+POINT_WORDS = 52
+WINDOW_PARTIAL_BYTES = PARTIAL_POINTS * POINT_WORDS * 4
+NUM_BUCKETS = 32768
+STAGE_NAMES = ("convert", "decompose", "sort", "accumulate", "reduce", "tail")
+
+OK, EINVAL, EHIP, ESCALAR, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
+
+_LIB = None
+
+
+class MsmError(RuntimeError):
+    """Raised for any non-zero return of the C ABI (the reference throws Error /
+    AssertionError, src/submission/implementation/cuzk/gpu.ts:7-10, submission.ts:405)."""
+
+    def __init__(self, code: int, what: str, detail: str = ""):
+        self.code = code
+        msg = "%s failed: %s (%d)" % (what, _strerror(code), code)
+        if detail:
+            msg += ": " + detail
+        super().__init__(msg)
+
+
+def library_path() -> str:
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.normpath(os.path.join(here, "..", "csrc", "libmsm377.so"))
+
+
+def load_library():
+    """Load csrc/libmsm377.so (built by __graft_entry__.build() / make -C csrc)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "msm377: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C webgpu-msm-bls12-377_amd/csrc`; there is no CPU fallback" % path
+        )
+    lib = ctypes.CDLL(path)
+    u8p, vp, u64, u32, i32 = ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    sigs = {
+        "msm377_version": (ctypes.c_char_p, []),
+        "msm377_strerror": (ctypes.c_char_p, [i32]),
+        "msm377_ctx_create": (i32, [i32, u64, ctypes.POINTER(vp)]),
+        "msm377_ctx_destroy": (None, [vp]),
+        "msm377_last_error": (ctypes.c_char_p, [vp]),
+        "msm377_g1_msm": (i32, [vp, u8p, u8p, u64, vp]),
+        "msm377_g1_msm_device": (i32, [vp, vp, vp, u64, vp]),
+        "msm377_g1_set_bases": (i32, [vp, u8p, u64]),
+        "msm377_g1_set_bases_device": (i32, [vp, vp, u64]),
+        "msm377_g1_msm_fixed_base": (i32, [vp, u8p, u64, vp]),
+        "msm377_g1_msm_fixed_base_device": (i32, [vp, vp, u64, vp]),
+        "msm377_g1_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
+        "msm377_g1_combine_partials": (i32, [vp, vp]),
+        "msm377_g1_generate_bases_device": (i32, [vp, u64, u64, vp]),
+        "msm377_ctx_set_stage_capture": (i32, [vp, i32]),
+        "msm377_g1_read_stage": (i32, [vp, u32, vp, vp, vp, vp]),
+        "msm377_g1_xyzz_to_affine": (i32, [vp, vp]),
+        "msm377_ctx_set_timing": (i32, [vp, i32]),
+        "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _strerror(code: int) -> str:
+    try:
+        return load_library().msm377_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "error"
+
+
+def combine_partials_bytes(partials: bytes) -> bytes:
+    """Host-only Horner + inversion over the 16 windows' partial records
+    (msm377_g1_combine_partials; replaces submission.ts:290-321)."""
+    if len(partials) != NUM_WINDOWS * WINDOW_PARTIAL_BYTES:
+        raise ValueError("expected %d bytes of partials" % (NUM_WINDOWS * WINDOW_PARTIAL_BYTES))
+    lib = load_library()
+    src = (ctypes.c_uint32 * (len(partials) // 4)).from_buffer_copy(partials)
+    out = ctypes.create_string_buffer(96)
+    rc = lib.msm377_g1_combine_partials(ctypes.addressof(src), ctypes.addressof(out))
+    if rc:
+        raise MsmError(rc, "msm377_g1_combine_partials")
+    return out.raw
+
+
+def xyzz_to_affine(words: Sequence[int]) -> bytes:
+    """One device-format XYZZ point (52 u32) -> 96-byte affine wire format."""
+    lib = load_library()
+    src = (ctypes.c_uint32 * POINT_WORDS)(*[int(w) for w in words])
+    out = ctypes.create_string_buffer(96)
+    rc = lib.msm377_g1_xyzz_to_affine(ctypes.addressof(src), ctypes.addressof(out))
+    if rc:
+        raise MsmError(rc, "msm377_g1_xyzz_to_affine")
+    return out.raw
+
+
+class MsmEngine:
+    """One HIP device context: workspace for up to ``max_points`` inputs, reusable across
+    calls (the reference re-acquires and destroys the device every call,
+    submission.ts:113,288)."""
+
+    def __init__(self, max_points: int, device: int = 0):
+        self._lib = load_library()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.msm377_ctx_create(int(device), int(max_points), ctypes.byref(self._ctx))
+        if rc:
+            self._ctx = ctypes.c_void_p()
+            raise MsmError(rc, "msm377_ctx_create", "device %d, max_points %d (is a HIP device visible?)" % (device, max_points))
+        self.max_points = int(max_points)
+        self.device = int(device)
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.msm377_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise MsmError(rc, what, self._lib.msm377_last_error(self._ctx).decode())
+
+    # -- G1 MSM --
+    def msm(self, points: bytes, scalars: bytes) -> bytes:
+        """compute_msm on host buffers; returns x||y (96 bytes)."""
+        n = _check_lengths(points, scalars)
+        out = ctypes.create_string_buffer(96)
+        self._check(self._lib.msm377_g1_msm(self._ctx, bytes(points), bytes(scalars), n, ctypes.addressof(out)), "msm377_g1_msm")
+        return out.raw
+
+    def msm_device(self, d_points: int, d_scalars: int, n: int) -> bytes:
+        """Inputs already in HBM (raw device pointers, wire format)."""
+        out = ctypes.create_string_buffer(96)
+        self._check(self._lib.msm377_g1_msm_device(self._ctx, d_points, d_scalars, int(n), ctypes.addressof(out)), "msm377_g1_msm_device")
+        return out.raw
+
+    def set_bases(self, points: bytes):
+        if len(points) % 96:
+            raise ValueError("points buffer length must be a multiple of 96")
+        self._check(self._lib.msm377_g1_set_bases(self._ctx, bytes(points), len(points) // 96), "msm377_g1_set_bases")
+
+    def set_bases_device(self, d_points: int, n: int):
+        self._check(self._lib.msm377_g1_set_bases_device(self._ctx, d_points, int(n)), "msm377_g1_set_bases_device")
+
+    def msm_fixed_base(self, scalars: bytes) -> bytes:
+        if len(scalars) % 32:
+            raise ValueError("scalars buffer length must be a multiple of 32")
+        out = ctypes.create_string_buffer(96)
+        self._check(self._lib.msm377_g1_msm_fixed_base(self._ctx, bytes(scalars), len(scalars) // 32, ctypes.addressof(out)), "msm377_g1_msm_fixed_base")
+        return out.raw
+
+    def msm_fixed_base_device(self, d_scalars: int, n: int) -> bytes:
+        out = ctypes.create_string_buffer(96)
+        self._check(self._lib.msm377_g1_msm_fixed_base_device(self._ctx, d_scalars, int(n), ctypes.addressof(out)), "msm377_g1_msm_fixed_base_device")
+        return out.raw
+
+    def window_partials_device(self, d_points: int, d_scalars: int, n: int, win_begin: int, win_count: int) -> bytes:
+        """Partial records of windows [win_begin, win_begin + win_count) (multi-GPU sharding)."""
+        out = ctypes.create_string_buffer(max(1, win_count) * WINDOW_PARTIAL_BYTES)
+        self._check(
+            self._lib.msm377_g1_window_partials_device(self._ctx, d_points, d_scalars, int(n), int(win_begin), int(win_count), ctypes.addressof(out)),
+            "msm377_g1_window_partials_device",
+        )
+        return out.raw[: win_count * WINDOW_PARTIAL_BYTES]
+
+    def generate_bases_device(self, seed: int, n: int, d_points_out: int):
+        self._check(self._lib.msm377_g1_generate_bases_device(self._ctx, int(seed) & (2**64 - 1), int(n), d_points_out), "msm377_g1_generate_bases_device")
+
+    # -- stage access (the reference's debug=true read-backs) --
+    def set_stage_capture(self, enabled: bool = True):
+        self._check(self._lib.msm377_ctx_set_stage_capture(self._ctx, int(bool(enabled))), "msm377_ctx_set_stage_capture")
+
+    def read_stage(self, slot: int, n: int, want=("digits", "row_ptr", "val_idx", "buckets")):
+        """Returns a dict of numpy arrays for window slot ``slot`` of the last call."""
+        import numpy as np
+
+        res = {}
+        digits = np.empty(n, dtype=np.uint16) if "digits" in want else None
+        row_ptr = np.empty(NUM_BUCKETS + 2, dtype=np.uint32) if "row_ptr" in want else None
+        val_idx = np.empty(n, dtype=np.uint32) if "val_idx" in want else None
+        buckets = np.empty((NUM_BUCKETS, POINT_WORDS), dtype=np.uint32) if "buckets" in want else None
+
+        def ptr(a):
+            return a.ctypes.data if a is not None else None
+
+        self._check(self._lib.msm377_g1_read_stage(self._ctx, int(slot), ptr(digits), ptr(row_ptr), ptr(val_idx), ptr(buckets)), "msm377_g1_read_stage")
+        for k, v in (("digits", digits), ("row_ptr", row_ptr), ("val_idx", val_idx), ("buckets", buckets)):
+            if v is not None:
+                res[k] = v
+        return res
+
+    # -- measurement --
+    def set_timing(self, enabled: bool = True):
+        self._check(self._lib.msm377_ctx_set_timing(self._ctx, int(bool(enabled))), "msm377_ctx_set_timing")
+
+    def stage_ms(self) -> dict:
+        arr = (ctypes.c_double * len(STAGE_NAMES))()
+        self._check(self._lib.msm377_ctx_get_stage_ms(self._ctx, ctypes.addressof(arr)), "msm377_ctx_get_stage_ms")
+        return dict(zip(STAGE_NAMES, list(arr)))
+
+
+def _check_lengths(points: bytes, scalars: bytes) -> int:
+    """input_size = scalars.length / 32 (submission.ts:91)."""
+    if len(scalars) % 32:
+        raise ValueError("scalars buffer length must be a multiple of 32")
+    n = len(scalars) // 32
+    if len(points) != 96 * n:
+        raise ValueError("points buffer must hold %d bytes (96 per scalar), got %d" % (96 * n, len(points)))
+    return n

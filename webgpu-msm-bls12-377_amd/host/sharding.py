@@ -1,0 +1,69 @@
+"""Window sharding across the GPUs of one node.
+
+The 16 window subtasks are independent after decomposition -- the reference already loops
+over them in groups of four (src/submission/submission.ts:199-224) -- so rank g computes a
+contiguous block of windows on its own GPU with no data-path collective, and ONE exchange
+follows: an all-gather of the per-window partial records (16 x 208 bytes per window,
+include/msm377.h) over RCCL/xGMI, a few KB in total, latency-bound.  Point addition is not an
+RCCL reduction op, so it is gather-then-add: the Horner combine runs on the host of every
+rank (msm377_g1_combine_partials).
+"""
+from typing import Callable, Optional, Tuple
+
+from .engine import NUM_WINDOWS, WINDOW_PARTIAL_BYTES, combine_partials_bytes
+
+
+def windows_for_rank(rank: int, world_size: int, num_windows: int = NUM_WINDOWS) -> Tuple[int, int]:
+    """(win_begin, win_count) of rank's contiguous window block; counts differ by at most one
+    and ranks beyond num_windows get (num_windows, 0)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, rem = divmod(num_windows, world_size)
+    count = base + (1 if rank < rem else 0)
+    begin = rank * base + min(rank, rem)
+    return begin, count
+
+
+def combine_partials(partials: bytes) -> bytes:
+    return combine_partials_bytes(partials)
+
+
+def sharded_msm(
+    partials_fn: Callable[[int, int], bytes],
+    rank: int,
+    world_size: int,
+    group=None,
+    device=None,
+) -> bytes:
+    """Run this rank's windows through ``partials_fn(win_begin, win_count)`` (normally
+    MsmEngine.window_partials_device bound to the resident inputs), all-gather the records and
+    return the affine result (96 bytes) on every rank.
+
+    With world_size == 1 no collective is issued.  ``device`` is the torch device of the
+    exchange buffer ("cuda:<local_rank>" under RCCL, "cpu" under gloo).
+    """
+    begin, count = windows_for_rank(rank, world_size)
+    mine = partials_fn(begin, count) if count else b""
+    if len(mine) != count * WINDOW_PARTIAL_BYTES:
+        raise ValueError("partials_fn returned %d bytes for %d windows" % (len(mine), count))
+    if world_size == 1:
+        return combine_partials_bytes(mine)
+
+    import torch
+    import torch.distributed as dist
+
+    max_count = (NUM_WINDOWS + world_size - 1) // world_size
+    slot = max_count * WINDOW_PARTIAL_BYTES
+    send = torch.zeros(slot, dtype=torch.uint8)
+    if count:
+        send[: len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+    if device is not None:
+        send = send.to(device)
+    recv = torch.empty(slot * world_size, dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    flat = recv.cpu().numpy().tobytes()
+    parts = []
+    for r in range(world_size):
+        _, c = windows_for_rank(r, world_size)
+        parts.append(flat[r * slot : r * slot + c * WINDOW_PARTIAL_BYTES])
+    return combine_partials_bytes(b"".join(parts))

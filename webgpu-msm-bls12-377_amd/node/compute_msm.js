@@ -1,0 +1,59 @@
+'use strict';
+// compute_msm for node (CommonJS twin of compute_msm.ts; runs as-is on node >= 12).
+// Same name, arguments and result as the reference entry point
+//   /root/reference/src/submission/submission.ts:85-90
+// with the WebGPU stage drivers replaced by one call into the N-API shim over
+// include/msm377.h.  Input forms (submission.ts:86-87): Buffer (the only form the harness
+// passes to this function, src/ui/AllBenchmarks.tsx:149-158), BigIntPoint[] / bigint[],
+// U32ArrayPoint[] / Uint32Array[] (most-significant-first words,
+// src/reference/webgpu/utils.ts:49-61).
+const path = require('path');
+const addon = require(path.join(__dirname, 'build', 'msm377_napi.node'));
+
+const leBufferToBigInt = (buf) => BigInt('0x' + Buffer.from(buf).reverse().toString('hex'));
+
+const bigIntToBufferLE = (v, bytes) => {
+  const hex = BigInt(v).toString(16).padStart(bytes * 2, '0');
+  return Buffer.from(hex, 'hex').reverse();
+};
+
+const u32WordsToBigInt = (words) => {
+  let v = BigInt(0);
+  for (const w of words) v = (v << BigInt(32)) | BigInt(w >>> 0);
+  return v;
+};
+
+const toBigInt = (v) => (typeof v === 'bigint' ? v : u32WordsToBigInt(v));
+
+const pointsToBuffer = (baseAffinePoints) => {
+  if (Buffer.isBuffer(baseAffinePoints)) return baseAffinePoints;
+  const parts = [];
+  for (const pt of baseAffinePoints) {
+    parts.push(bigIntToBufferLE(toBigInt(pt.x), 48));
+    parts.push(bigIntToBufferLE(toBigInt(pt.y), 48));
+  }
+  return Buffer.concat(parts);
+};
+
+const scalarsToBuffer = (scalars) => {
+  if (Buffer.isBuffer(scalars)) return scalars;
+  return Buffer.concat(Array.from(scalars, (s) => bigIntToBufferLE(toBigInt(s), 32)));
+};
+
+const compute_msm = async (baseAffinePoints, scalars, log_result = true, force_recompile = false) => {
+  void force_recompile; // kernels are compiled ahead of time for gfx950; nothing to recompile
+  const scalarsBuf = scalarsToBuffer(scalars);
+  const input_size = scalarsBuf.length / 32;
+  if (input_size === 0) {
+    return { x: BigInt(0), y: BigInt(1) };
+  }
+  const pointsBuf = pointsToBuffer(baseAffinePoints);
+  const out = await addon.computeMsm(pointsBuf, scalarsBuf);
+  const r = { x: leBufferToBigInt(out.slice(0, 48)), y: leBufferToBigInt(out.slice(48, 96)) };
+  if (log_result) {
+    console.log(r);
+  }
+  return r;
+};
+
+module.exports = { compute_msm, pointsToBuffer, scalarsToBuffer, version: addon.version };
