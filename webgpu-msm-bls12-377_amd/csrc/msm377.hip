@@ -44,6 +44,9 @@ constexpr uint32_t REC_WORDS = 32; // one base record, 128 bytes
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
 constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) pairs: one 131 KB LDS histogram per CU
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
+constexpr uint32_t SEG = 64;               // entries per accumulation work item (one thread); longer rows are split
+constexpr uint32_t SEG_BINS = SEG + 1;     // work items are counting-sorted by length 0..SEG
+constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
 
 // ------------------------------------------------------------------ device helpers ----
 
@@ -234,19 +237,109 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ d
   }
 }
 
-// Bucket accumulation: one thread per (window slot, bucket t = 1..32768).  Walks the CSR row
-// of key t and adds +P for digit +t, -P for digit -t (the reference's thread handles rows
-// t+h and h-t and negates the second sum, smvp_bls12_377.template.wgsl:96-133; its bucket 0 =
-// digit -2^15 is bucket 32768 here).  The next record is requested before the current mixed
-// addition so the gather latency hides under ~10 field multiplications.
+// ---- bucket accumulation (the reference's SMVP, smvp_bls12_377.template.wgsl:72-160) ----
+//
+// A bucket's CSR row (key t: +P for digit +t, -P for digit -t; the reference's thread walks
+// rows t+h and h-t and negates the second sum, :96-133; its bucket 0 = digit -2^15 is bucket
+// 32768 here) is cut into work items of at most SEG entries, one thread each.  Row lengths
+// are Poisson(n/2^15) in 15 windows but ~7x longer in the top window (13 significant bits),
+// and a wave runs as long as its longest lane, so the items are counting-sorted by length,
+// longest first, across ALL window slots (k_work_hist / k_work_scan / k_work_scatter): the
+// lanes of a wave then finish together and no serial chain exceeds SEG mixed additions.
+// Item 0 of a row writes the bucket; items s >= 1 write overflow partials that
+// k_merge_split_rows adds back (rows longer than SEG: the top window always, any window under
+// skewed scalars -- the load balancing the reference left out, README.md:543-547).
+
+struct WorkItem {
+  uint32_t row;  // ws * NB + t   (bucket index t <-> key t + 1)
+  uint32_t seg;  // entries [seg * SEG, seg * SEG + SEG) of the row
+};
+
+__device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr, uint32_t row) {
+  const uint32_t* rp = row_ptr + (size_t)(row / NB) * RP + (row % NB);
+  return rp[2] - rp[1];
+}
+
+// Thread per row: length histogram of its work items (LDS, then one global atomic per bin and
+// block); rows with more than one item reserve overflow slots and join the split-row list.
+__global__ void __launch_bounds__(256) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ work_hist,
+                                                   uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
+                                                   uint32_t* __restrict__ split_rows) {
+  __shared__ uint32_t lh[SEG_BINS];
+  const uint32_t tid = threadIdx.x, row = blockIdx.x * 256 + tid;
+  if (tid < SEG_BINS) lh[tid] = 0;
+  __syncthreads();
+  if (row < rows) {
+    const uint32_t len = row_len(row_ptr, row);
+    const uint32_t nfull = len / SEG, rem = len % SEG;
+    if (nfull) atomicAdd(&lh[SEG], nfull);
+    if (rem || len == 0) atomicAdd(&lh[rem], 1u);
+    const uint32_t nseg = nfull + ((rem || len == 0) ? 1u : 0u);
+    if (nseg > 1) {
+      row_ovf_base[row] = atomicAdd(&counters[1], nseg - 1);
+      split_rows[atomicAdd(&counters[0], 1u)] = row;
+    }
+  }
+  __syncthreads();
+  if (tid < SEG_BINS && lh[tid]) atomicAdd(&work_hist[tid], lh[tid]);
+}
+
+// One wave: cursor[b] = number of items longer than b (descending order), total item count.
+__global__ void __launch_bounds__(128) k_work_scan(const uint32_t* __restrict__ work_hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ total) {
+  __shared__ uint32_t h[SEG_BINS];
+  const uint32_t tid = threadIdx.x;
+  if (tid < SEG_BINS) h[tid] = work_hist[tid];
+  __syncthreads();
+  if (tid < SEG_BINS) {
+    uint32_t c = 0;
+    for (uint32_t b = tid + 1; b < SEG_BINS; b++) c += h[b];
+    cursor[tid] = c;
+    if (tid == 0) *total = c + h[0];
+  }
+}
+
+// Thread per row again: claims its slots in the sorted work list.
+__global__ void __launch_bounds__(256) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ cursor,
+                                                      WorkItem* __restrict__ work) {
+  __shared__ uint32_t lh[SEG_BINS];
+  __shared__ uint32_t lbase[SEG_BINS];
+  const uint32_t tid = threadIdx.x, row = blockIdx.x * 256 + tid;
+  if (tid < SEG_BINS) lh[tid] = 0;
+  __syncthreads();
+  uint32_t nfull = 0, rem = 0, rank_full = 0, rank_rem = 0;
+  bool has_rem = false;
+  if (row < rows) {
+    const uint32_t len = row_len(row_ptr, row);
+    nfull = len / SEG;
+    rem = len % SEG;
+    has_rem = rem || len == 0;
+    if (nfull) rank_full = atomicAdd(&lh[SEG], nfull);
+    if (has_rem) rank_rem = atomicAdd(&lh[rem], 1u);
+  }
+  __syncthreads();
+  if (tid < SEG_BINS && lh[tid]) lbase[tid] = atomicAdd(&cursor[tid], lh[tid]);
+  __syncthreads();
+  if (row < rows) {
+    for (uint32_t s = 0; s < nfull; s++) work[lbase[SEG] + rank_full + s] = WorkItem{row, s};
+    if (has_rem) work[lbase[rem] + rank_rem] = WorkItem{row, nfull};
+  }
+}
+
+// One thread per work item.  The next record is requested before the current mixed addition
+// so the gather latency hides under ~10 field multiplications.
 __global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
-                                                       const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n) {
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t ws = g / NB, t = g % NB;  // bucket index t <-> key t + 1
+                                                       const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
+                                                       const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
+                                                       const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf) {
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= *work_total) return;
+  const WorkItem it = work[v];
+  const uint32_t ws = it.row / NB, t = it.row % NB;
   const uint32_t* rp = row_ptr + (size_t)ws * RP;
   const uint32_t* vi = val_idx + (size_t)ws * n;
-  uint32_t k = rp[t + 1];
-  const uint32_t end = rp[t + 2];
+  const uint32_t row_end = rp[t + 2];
+  uint32_t k = rp[t + 1] + it.seg * SEG;
+  const uint32_t end = (row_end - k > SEG) ? k + SEG : row_end;
   G1XYZZ acc = g1_identity();
   if (k < end) {
     uint32_t e = vi[k];
@@ -265,27 +358,110 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restric
       if (!more) break;
     }
   }
-  store_bucket(buckets, ws, t, acc);
+  if (it.seg == 0) {
+    store_bucket(buckets, ws, t, acc);
+  } else {
+    uint4* d = reinterpret_cast<uint4*>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * PT_WORDS);
+    uint32_t w[PT_WORDS];
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      w[j] = acc.x.l[j];
+      w[13 + j] = acc.y.l[j];
+      w[26 + j] = acc.zz.l[j];
+      w[39 + j] = acc.zzz.l[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 13; q++) d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
 }
 
-// Bucket reduction, level r of 15.  Per window the buckets B[0..NB) (B[i] has weight i+1) are
-// reduced in place to  B[0] = sum of all buckets  and  B[2^l] = sum of buckets whose index has
-// bit l set  (l = 0..14), so that  sum_i (i+1) B[i] = B[0] + sum_l 2^l B[2^l].
-// Level r performs, for every offset o in {0, 2^0, .., 2^(r-1)} and k < NB/2^(r+1):
-//     B[o + k 2^(r+1)] += B[o + k 2^(r+1) + 2^r]
-// (o = 0: pairwise sums of the running blocks; o = 2^l: pairwise tree over level l's odd
-// blocks).  All (x, y) pairs of one level are disjoint.  Total work 2 NB additions per window
-// -- the same as the reference's running sum (bpr.template.wgsl:99-107) -- at depth 15
-// instead of 2 * 128 + a 15-bit double-and-add per thread.
+// Thread per split row: bucket += its overflow partials (serial; 3 additions per row of the
+// top window at n = 2^20, more only under heavy skew).
+__global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
+                                                             const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
+                                                             const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf) {
+  const uint32_t count = counters[0];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+    const uint32_t row = split_rows[i];
+    const uint32_t len = row_len(row_ptr, row);
+    const uint32_t nseg = (len + SEG - 1) / SEG;
+    const uint32_t ws = row / NB, t = row % NB;
+    G1XYZZ acc = load_bucket(buckets, ws, t);
+    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * PT_WORDS;
+    for (uint32_t s = 1; s < nseg; s++) {
+      uint32_t w[PT_WORDS];
+      load_words16(src + (size_t)(s - 1) * PT_WORDS, w, 13);
+      G1XYZZ o;
+#pragma unroll
+      for (int j = 0; j < 13; j++) {
+        o.x.l[j] = w[j];
+        o.y.l[j] = w[13 + j];
+        o.zz.l[j] = w[26 + j];
+        o.zzz.l[j] = w[39 + j];
+      }
+      acc = g1_add(acc, o);
+    }
+    store_bucket(buckets, ws, t, acc);
+  }
+}
+
+// Bucket reduction.  Per window the buckets B[0..NB) (B[i] has weight i+1) are reduced in
+// place to  B[0] = sum of all buckets  and  B[2^b] = sum of the buckets whose index has bit b
+// set  (b = 0..14), so that  sum_i (i+1) B[i] = B[0] + sum_b 2^b B[2^b]  -- the weights are
+// applied by the host's Horner pass, not by per-thread double-and-add as in the reference
+// (bpr.template.wgsl:125-173).  Bits are peeled from the top: level r (r = 0..14) folds the
+// upper half of the running block [0, NB/2^r) onto its lower half,
+//     B[k] += B[k + NB/2^(r+1)],            k < NB/2^(r+1),
+// which leaves the untouched upper half [NB/2^(r+1), NB/2^r) = "index bit 14-r set" as a
+// contiguous list that later levels halve the same way,
+//     B[lo + k] += B[lo + k + NB/2^(r+1)],  lo = NB/2^(r'+1) for every earlier level r' < r.
+// Every access is unit-stride across lanes (limb-major bucket layout).  Total work 2 NB
+// additions per window -- the same as the reference's running sum (bpr.template.wgsl:99-107) --
+// at depth 15 instead of 2 * 128 serial additions plus a 15-bit scalar multiplication.
+//
+// k_reduce_first fuses levels 0..2 in registers: thread k < NB/8 loads the 8 buckets
+// k + j NB/8 (j = j2 j1 j0 are index bits 14, 13, 12) and emits
+//     S = sum_j B_j -> B[k],   bit 14: B4+..+B7 -> B[NB/2 + k],
+//     bit 13: B2+B3+B6+B7 -> B[NB/4 + k],   bit 12: B1+B3+B5+B7 -> B[NB/8 + k]
+// with 11 additions (one wave per SIMD: it needs ~6 live points).
+__global__ void __launch_bounds__(256, 1) k_reduce_first(uint32_t* __restrict__ buckets) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // < NB / 8
+  const uint32_t ws = blockIdx.y;
+  constexpr uint32_t Q = NB / 8;
+  G1XYZZ b0 = load_bucket(buckets, ws, k);
+  G1XYZZ b1 = load_bucket(buckets, ws, k + Q);
+  G1XYZZ s0123 = g1_add(b0, b1);
+  G1XYZZ p12 = b1;
+  G1XYZZ b2 = load_bucket(buckets, ws, k + 2 * Q);
+  G1XYZZ b3 = load_bucket(buckets, ws, k + 3 * Q);
+  G1XYZZ s23 = g1_add(b2, b3);
+  p12 = g1_add(p12, b3);
+  s0123 = g1_add(s0123, s23);
+  G1XYZZ b4 = load_bucket(buckets, ws, k + 4 * Q);
+  G1XYZZ b5 = load_bucket(buckets, ws, k + 5 * Q);
+  G1XYZZ s4567 = g1_add(b4, b5);
+  p12 = g1_add(p12, b5);
+  G1XYZZ b6 = load_bucket(buckets, ws, k + 6 * Q);
+  G1XYZZ b7 = load_bucket(buckets, ws, k + 7 * Q);
+  G1XYZZ s67 = g1_add(b6, b7);
+  p12 = g1_add(p12, b7);
+  store_bucket(buckets, ws, k + Q, p12);
+  store_bucket(buckets, ws, k + 2 * Q, g1_add(s23, s67));
+  s4567 = g1_add(s4567, s67);
+  store_bucket(buckets, ws, k + 4 * Q, s4567);
+  store_bucket(buckets, ws, k, g1_add(s0123, s4567));
+}
+
+// One level r >= 3 of the reduction (see above): (r + 1) lists of NB/2^(r+1) pair-additions.
 __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   const uint32_t ws = blockIdx.y;
   if (g >= ops_per_window) return;
-  const uint32_t per_off = NB >> (r + 1);
-  const uint32_t oi = g / per_off, kk = g % per_off;
-  const uint32_t o = oi == 0 ? 0u : (1u << (oi - 1));
-  const uint32_t x = o + (kk << (r + 1));
-  const uint32_t y = x + (1u << r);
+  const uint32_t half = NB >> (r + 1);
+  const uint32_t oi = g / half, kk = g % half;
+  const uint32_t lo = oi == 0 ? 0u : (NB >> oi);  // list of level r' = oi - 1 starts at NB/2^(r'+1)
+  const uint32_t x = lo + kk;
+  const uint32_t y = x + half;
   G1XYZZ a = load_bucket(buckets, ws, x);
   G1XYZZ b = load_bucket(buckets, ws, y);
   store_bucket(buckets, ws, x, g1_add(a, b));
@@ -359,6 +535,11 @@ struct msm377_ctx {
   uint32_t* d_buckets = nullptr;      // 16 x 52 x NB
   uint32_t* d_buckets_snap = nullptr; // stage capture only
   uint32_t* d_partials = nullptr;     // 16 x 16 x 52
+  WorkItem* d_work = nullptr;         // sorted accumulation work items (<= 16 NB + 16 cap / SEG)
+  uint32_t* d_work_meta = nullptr;    // [0..SEG] length histogram, [SEG_BINS..] cursors, then total, split-row count, overflow count
+  uint32_t* d_row_ovf_base = nullptr; // 16 x NB
+  uint32_t* d_split_rows = nullptr;   // 16 x NB
+  uint32_t* d_ovf = nullptr;          // overflow partial points, 52 words each (<= 16 cap / SEG)
   int* d_err = nullptr;
   // pinned host
   uint32_t* h_partials = nullptr;
@@ -438,7 +619,26 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
   }
   {
     StageTimer t(ctx, MSM377_STAGE_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, dim3(wc * (NB / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx, ctx->d_bases, ctx->d_buckets, n);
+    const uint32_t rows = wc * NB;
+    uint32_t* meta = ctx->d_work_meta;
+    uint32_t* work_hist = meta;
+    uint32_t* cursor = meta + SEG_BINS;
+    uint32_t* total = meta + 2 * SEG_BINS;
+    uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
+    HIP_TRY(ctx, hipMemsetAsync(meta, 0, (size_t)(2 * SEG_BINS + 4) * 4, st));
+    hipLaunchKernelGGL(k_work_hist, dim3(rows / 256), dim3(256), 0, st, ctx->d_row_ptr, rows, work_hist, ctx->d_row_ovf_base, counters,
+                       ctx->d_split_rows);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(128), 0, st, work_hist, cursor, total);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 256), dim3(256), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
+    HIP_TRY(ctx, hipGetLastError());
+    const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx, ctx->d_bases,
+                       ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_merge_split_rows, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters, ctx->d_split_rows,
+                       ctx->d_row_ovf_base, ctx->d_ovf);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->capture) {
@@ -446,7 +646,9 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
   }
   {
     StageTimer t(ctx, MSM377_STAGE_REDUCE);
-    for (uint32_t r = 0; r < TREE_LEVELS; r++) {
+    hipLaunchKernelGGL(k_reduce_first, dim3(NB / 8 / 256, wc), dim3(256), 0, st, ctx->d_buckets);
+    HIP_TRY(ctx, hipGetLastError());
+    for (uint32_t r = 3; r < TREE_LEVELS; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       hipLaunchKernelGGL(k_tree_step, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
       HIP_TRY(ctx, hipGetLastError());
@@ -539,6 +741,11 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
   dalloc((void**)&ctx->d_partials, (size_t)MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
+  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG + 1) * sizeof(WorkItem));
+  dalloc((void**)&ctx->d_work_meta, (size_t)(2 * SEG_BINS + 4) * 4);
+  dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
+  dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
+  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG + 1) * PT_WORDS * 4);
   dalloc((void**)&ctx->d_err, sizeof(int));
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, sizeof(int)) == hipSuccess;
@@ -560,7 +767,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_hist_chunk, ctx->d_tot,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_err};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
