@@ -93,6 +93,18 @@ int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
  * output, written in wire format to device memory d_points_out (n x 96 bytes). */
 int msm377_g1_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out);
 
+/* ---- Twisted-Edwards BLS12 ("Edwards-BLS12": a = -1, d = 3021 over the BLS12-377 scalar field;
+ *      BASELINE.json config 3; the reference's orphaned Edwards shaders,
+ *      src/submission/miscellaneous/wgsl/add_points_any_a.template.wgsl:24-71,
+ *      src/reference/params/AleoConstants.ts:2-5) --------------------------------------------
+ * Wire format (README.md:299-301): points n x 64 bytes = x || y, 32-byte little-endian each;
+ * scalars as above; result 64 bytes x || y; the neutral element (and the empty input) is
+ * x = 0, y = 1.  Same pipeline and workspace as G1 (extended coordinates, add-2008-hwcd-3). */
+int msm377_ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[64]);
+int msm377_ed_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[64]);
+/* Synthetic Edwards inputs: P_i = [a_i]G_ed (src/reference/utils/FieldMath.ts:108-109), 64 bytes each. */
+int msm377_ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out);
+
 /* ---- stage access for parity tests (the reference's debug=true read-backs,
  *      submission.ts:466-520, 613-641, 724-798) ------------------------------------------- */
 

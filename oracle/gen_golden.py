@@ -76,9 +76,39 @@ def cases():
     return out
 
 
+def ed_random_points(seed, n):
+    g = R.splitmix64(seed)
+    return [R.ed_mul(R.ED_G, next(g) or 1) for _ in range(n)]
+
+
+def ed_cases():
+    """Edwards-BLS12 cases (64-byte points).  Scalars below the subgroup order
+    (src/reference/params/AleoConstants.ts:5)."""
+    out = {}
+    out["ed_n1_gen"] = ([R.ED_G], [1])
+    p = ed_random_points(0xED, 2)
+    out["ed_n2_cancel"] = ([p[0], R.ed_neg(p[0])], [987654321987654321, 987654321987654321])
+    out["ed_n24_random"] = (ed_random_points(0xED + 24, 24), R.rand_scalars(0x5CA1A5 + 24, 24, R.ED_SUBGROUP))
+    ks = [0, 1, R.ED_SUBGROUP - 1, 1 << 15, (1 << 15) - 1, (1 << 16) - 1, 1 << 16,
+          0x8000800080008000800080008000800080008000800080008000800080008000 % R.ED_SUBGROUP,
+          0x7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF % R.ED_SUBGROUP, 1 << 250]
+    out["ed_n%d_edge_scalars" % len(ks)] = (ed_random_points(0xED + 10, len(ks)), ks)
+    out["ed_n32_same_point"] = ([p[1]] * 32, R.rand_scalars(0x5CA1A5 + 32, 32, R.ED_SUBGROUP))
+    out["ed_n256_random"] = (ed_random_points(0xED, 256), R.rand_scalars(0x5CA1A5, 256, R.ED_SUBGROUP))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     manifest = {}
+    for name, (pts, ks) in ed_cases().items():
+        assert len(pts) == len(ks) and all(R.ed_on_curve(p) for p in pts)
+        exp = R.ed_msm_naive(pts, ks)
+        blob = R.ed_encode_points(pts) + R.encode_scalars(ks) + R.ed_encode_result(exp)
+        with open(os.path.join(OUT, name + ".bin"), "wb") as f:
+            f.write(blob)
+        manifest[name] = {"n": len(pts), "expected_identity": exp == R.ED_ID}
+        print(name, len(pts), hex(exp[0])[:18])
     for name, (pts, ks) in cases().items():
         assert len(pts) == len(ks)
         assert all(R.on_curve(p) for p in pts)

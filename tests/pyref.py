@@ -227,3 +227,41 @@ def ed_encode_points(points):
 
 def ed_encode_result(pt):
     return pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")
+
+
+def _sqrt_mod_q(a):
+    """Tonelli-Shanks in Fq (q - 1 = 2^47 * odd)."""
+    a %= Q
+    if a == 0:
+        return 0
+    if pow(a, (Q - 1) // 2, Q) != 1:
+        return None
+    s, t = 0, Q - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (Q - 1) // 2, Q) != Q - 1:
+        z += 1
+    m, c, tt, r = s, pow(z, t, Q), pow(a, t, Q), pow(a, (t + 1) // 2, Q)
+    while tt != 1:
+        i, x = 0, tt
+        while x != 1:
+            x = x * x % Q
+            i += 1
+        b = pow(c, 1 << (m - i - 1), Q)
+        m, c = i, b * b % Q
+        tt, r = tt * c % Q, r * b % Q
+    return r
+
+
+def ed_point_from_x(x):
+    """getPointFromX (src/reference/utils/FieldMath.ts:31-55): y^2 = (a x^2 - 1)/(d x^2 - 1), the root
+    that puts the point in the prime-order subgroup."""
+    xx = x * x % Q
+    y2 = (ED_A * xx - 1) * pow(ED_D * xx - 1, -1, Q) % Q
+    y = _sqrt_mod_q(y2)
+    assert y is not None
+    for cand in (y, (-y) % Q):
+        if ed_mul((x, cand), ED_SUBGROUP) == ED_ID:
+            return (x, cand)
+    raise ValueError("no subgroup point with this x")

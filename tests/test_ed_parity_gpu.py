@@ -1,0 +1,87 @@
+"""GPU parity for the Twisted-Edwards BLS12 path (BASELINE.json config 3):
+HIP engine through the C ABI against the Edwards oracle, the golden vectors and a closed form at 2^20.
+Bit-exact.  Run with `pytest -m gpu`."""
+import ctypes
+import random
+
+import pytest
+
+import pyref as R
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(buf: bytes):
+    import torch
+
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+
+
+def test_golden_vectors(engine, golden):
+    for name, case in golden.items():
+        if name.startswith("ed_"):
+            assert engine.ed_msm(case["points"], case["scalars"]) == case["expected"], name
+
+
+def test_empty_input_is_the_neutral_element(engine):
+    assert engine.ed_msm(b"", b"") == R.ed_encode_result(R.ED_ID)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 65, 257, 1000, 4097])
+def test_ragged_sizes_against_oracle(engine, oracle, n):
+    rnd = random.Random(n)
+    pts = util.oracle_ed_gen_points(oracle, n, rnd.randrange(1, 1 << 200), rnd.randrange(1, 1 << 200))
+    ks = R.encode_scalars(R.rand_scalars(500 + n, n, R.ED_SUBGROUP))
+    assert engine.ed_msm(pts, ks) == util.oracle_ed_msm(oracle, pts, ks)
+
+
+def test_2_16_against_reference_sized_oracle(engine, oracle):
+    n = 1 << 16
+    pts = util.oracle_ed_gen_points(oracle, n, 0xABCDEF, 0x13579B)
+    ks = R.encode_scalars(R.rand_scalars(16, n, R.ED_SUBGROUP))
+    exp = util.oracle_ed_msm(oracle, pts, ks)  # 16-bit windows, 256 BPR threads
+    assert engine.ed_msm(pts, ks) == exp
+    d_p, d_s = dev(pts), dev(ks)
+    assert engine.ed_msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == exp
+
+
+def test_one_repeated_point_and_opposites(engine):
+    """The complete addition law must cover P + P and P + (-P) inside buckets."""
+    p = R.ed_mul(R.ED_G, 123456789)
+    pts = [p] * 500 + [R.ed_neg(p)] * 500
+    ks = R.rand_scalars(77, 1000, R.ED_SUBGROUP)
+    total = (sum(ks[:500]) - sum(ks[500:])) % R.ED_SUBGROUP
+    assert engine.ed_msm(R.ed_encode_points(pts), R.encode_scalars(ks)) == R.ed_encode_result(R.ed_mul(p, total))
+
+
+def test_generate_bases(engine):
+    import torch
+
+    n, seed = 24, 0xED
+    out = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    engine.ed_generate_bases_device(seed, n, out.data_ptr())
+    raw = out.cpu().numpy().tobytes()
+    g = R.splitmix64(seed)
+    for i in range(n):
+        pt = (int.from_bytes(raw[64 * i : 64 * i + 32], "little"), int.from_bytes(raw[64 * i + 32 : 64 * i + 64], "little"))
+        assert pt == R.ed_mul(R.ED_G, next(g))
+
+
+def test_full_size_2_20_closed_form(engine, oracle):
+    """P_i = [a0 + i d]G_ed: the 2^20-point MSM equals one scalar multiplication of the generator."""
+    n = 1 << 20
+    a0, d = 0x1234567890ABCDEF12345, 0xFEDCBA098765
+    pts = util.oracle_ed_gen_points(oracle, n, a0, d)
+    ks_int = R.rand_scalars(0x5CA1A5, n, R.ED_SUBGROUP)
+    total = sum(k * (a0 + i * d) for i, k in enumerate(ks_int)) % R.ED_SUBGROUP
+    exp = ctypes.create_string_buffer(64)
+    assert oracle.oracle_ed_scalar_mul(R.ed_encode_points([R.ED_G]), total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
+    d_p, d_s = dev(pts), dev(R.encode_scalars(ks_int))
+    engine.set_timing(True)
+    try:
+        got = engine.ed_msm_device(d_p.data_ptr(), d_s.data_ptr(), n)
+        print("edwards stage ms:", engine.stage_ms())
+    finally:
+        engine.set_timing(False)
+    assert got == exp.raw

@@ -90,6 +90,8 @@ def test_test_cases_ts_answers_are_on_the_curve(oracle):
 
 def test_golden_vectors(oracle, golden):
     for name, case in golden.items():
+        if not name.startswith("g1_"):
+            continue
         for fn in ("oracle_g1_msm", "oracle_g1_msm_naive"):
             assert util.oracle_msm(oracle, case["points"], case["scalars"], fn) == case["expected"], (name, fn)
 

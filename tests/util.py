@@ -38,6 +38,13 @@ def load_oracle():
     lib.oracle_g1_gen_points_arith.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
     lib.oracle_g1_generator.argtypes = [ctypes.c_void_p]
     lib.oracle_g1_generator.restype = None
+    for fn in ("oracle_ed_msm", "oracle_ed_msm_naive"):
+        getattr(lib, fn).argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.oracle_ed_msm_params.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    lib.oracle_ed_scalar_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p]
+    lib.oracle_ed_add_affine.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+    lib.oracle_ed_on_curve.argtypes = [ctypes.c_char_p]
+    lib.oracle_ed_gen_points_arith.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
     lib.oracle_fp_ops.argtypes = [ctypes.c_char_p] * 2 + [ctypes.c_void_p] * 3
     lib.oracle_fp_ops.restype = None
     lib.oracle_fp_mont_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -70,16 +77,32 @@ def oracle_gen_points(lib, n, a0, delta) -> bytes:
     return out.raw
 
 
+def oracle_ed_msm(lib, points: bytes, scalars: bytes, fn="oracle_ed_msm") -> bytes:
+    n = len(scalars) // 32
+    out = ctypes.create_string_buffer(64)
+    rc = getattr(lib, fn)(points, scalars, n, ctypes.addressof(out))
+    assert rc == 0, rc
+    return out.raw
+
+
+def oracle_ed_gen_points(lib, n, a0, delta) -> bytes:
+    out = ctypes.create_string_buffer(64 * n)
+    rc = lib.oracle_ed_gen_points_arith(n, R.ed_encode_points([R.ED_G]), int(a0).to_bytes(32, "little"), int(delta).to_bytes(32, "little"), ctypes.addressof(out))
+    assert rc == 0, rc
+    return out.raw
+
+
 def load_golden():
     with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
         manifest = json.load(f)
     cases = {}
     for name, meta in manifest.items():
         n = meta["n"]
+        psz = 64 if name.startswith("ed_") else 96  # Edwards cases carry 64-byte points / results
         with open(os.path.join(GOLDEN_DIR, name + ".bin"), "rb") as f:
             blob = f.read()
-        assert len(blob) == 128 * n + 96
-        cases[name] = {"n": n, "points": blob[: 96 * n], "scalars": blob[96 * n : 128 * n], "expected": blob[128 * n :]}
+        assert len(blob) == (psz + 32) * n + psz
+        cases[name] = {"n": n, "points": blob[: psz * n], "scalars": blob[psz * n : (psz + 32) * n], "expected": blob[(psz + 32) * n :]}
     return cases
 
 

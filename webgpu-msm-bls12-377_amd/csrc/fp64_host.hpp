@@ -1,22 +1,25 @@
-// Host-only BLS12-377 base field on 6 x 64-bit words (Montgomery radix 2^384) for the CPU
-// tail of the pipeline: Horner over the window/bit-plane partial sums and the single field
-// inversion of the result (replaces the reference's BigInt tail with 4096 inversions,
+// Host-only prime fields on 64-bit words (Montgomery radix 2^(64 NW)) for the CPU tail of
+// the pipeline: Horner over the window / bit-plane partial sums and the single field inversion
+// of the result (replaces the reference's BigInt tail with 4096 inversions,
 // src/submission/submission.ts:290-321 and cuzk/bls12_377.ts:41-63).  Same static interface
-// as Field<> in field29.hpp so G1T<> works over it.
+// as Field<> in field29.hpp so G1T<> / EdT<> work over it.
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
+#include "ed_ext.hpp"
 #include "field29.hpp"
 #include "g1_xyzz.hpp"
 
 namespace msm377 {
 
-struct Fp64 {
+// C: 64-bit constants (G1Consts64 / EdConsts64); F29: the device-format field of the same modulus.
+template <class C, class F29>
+struct FieldHost64 {
+  static constexpr int NW = C::NW;
   struct El {
-    uint64_t v[6];
+    uint64_t v[NW];
   };
-  using C = G1Consts64;
   typedef unsigned __int128 u128;
 
   static El zero() {
@@ -24,19 +27,25 @@ struct Fp64 {
     memset(&r, 0, sizeof r);
     return r;
   }
-  static El one() {
+  static El from_const(const uint64_t (&c)[NW]) {
     El r;
-    for (int i = 0; i < 6; i++) r.v[i] = C::ONE[i];
+    for (int i = 0; i < NW; i++) r.v[i] = c[i];
     return r;
   }
-  static bool is_zero(const El& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5]) == 0; }
-  static bool eq(const El& a, const El& b) {
+  static El one() { return from_const(C::ONE); }
+  static bool is_zero(const El& a) {
     uint64_t acc = 0;
-    for (int i = 0; i < 6; i++) acc |= a.v[i] ^ b.v[i];
+    for (int i = 0; i < NW; i++) acc |= a.v[i];
     return acc == 0;
   }
+  static bool eq(const El& a, const El& b) {
+    uint64_t acc = 0;
+    for (int i = 0; i < NW; i++) acc |= a.v[i] ^ b.v[i];
+    return acc == 0;
+  }
+  static El select(bool c, const El& a, const El& b) { return c ? a : b; }
   static bool geq_p(const uint64_t* a) {
-    for (int i = 5; i >= 0; i--) {
+    for (int i = NW - 1; i >= 0; i--) {
       if (a[i] > C::MOD[i]) return true;
       if (a[i] < C::MOD[i]) return false;
     }
@@ -44,7 +53,7 @@ struct Fp64 {
   }
   static void sub_p(uint64_t* a) {
     uint64_t borrow = 0;
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < NW; i++) {
       u128 d = (u128)a[i] - C::MOD[i] - borrow;
       a[i] = (uint64_t)d;
       borrow = (uint64_t)(d >> 64) & 1;
@@ -53,7 +62,7 @@ struct Fp64 {
   static El add(const El& a, const El& b) {
     El r;
     uint64_t carry = 0;
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < NW; i++) {
       u128 s = (u128)a.v[i] + b.v[i] + carry;
       r.v[i] = (uint64_t)s;
       carry = (uint64_t)(s >> 64);
@@ -65,14 +74,14 @@ struct Fp64 {
   static El sub(const El& a, const El& b) {
     El r;
     uint64_t borrow = 0;
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < NW; i++) {
       u128 d = (u128)a.v[i] - b.v[i] - borrow;
       r.v[i] = (uint64_t)d;
       borrow = (uint64_t)(d >> 64) & 1;
     }
     if (borrow) {
       uint64_t carry = 0;
-      for (int i = 0; i < 6; i++) {
+      for (int i = 0; i < NW; i++) {
         u128 s = (u128)r.v[i] + C::MOD[i] + carry;
         r.v[i] = (uint64_t)s;
         carry = (uint64_t)(s >> 64);
@@ -81,68 +90,71 @@ struct Fp64 {
     return r;
   }
   static El neg(const El& a) { return is_zero(a) ? a : sub(zero(), a); }
+  static El cneg(const El& a, bool c) { return c ? neg(a) : a; }
   static El mul(const El& a, const El& b) {
-    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 6; i++) {
+    uint64_t t[NW + 2];
+    for (int i = 0; i < NW + 2; i++) t[i] = 0;
+    for (int i = 0; i < NW; i++) {
       uint64_t carry = 0;
-      for (int j = 0; j < 6; j++) {
+      for (int j = 0; j < NW; j++) {
         u128 acc = (u128)a.v[j] * b.v[i] + t[j] + carry;
         t[j] = (uint64_t)acc;
         carry = (uint64_t)(acc >> 64);
       }
-      u128 acc = (u128)t[6] + carry;
-      t[6] = (uint64_t)acc;
-      t[7] = (uint64_t)(acc >> 64);
+      u128 acc = (u128)t[NW] + carry;
+      t[NW] = (uint64_t)acc;
+      t[NW + 1] = (uint64_t)(acc >> 64);
       uint64_t m = t[0] * C::N0;
       acc = (u128)m * C::MOD[0] + t[0];
       carry = (uint64_t)(acc >> 64);
-      for (int j = 1; j < 6; j++) {
+      for (int j = 1; j < NW; j++) {
         acc = (u128)m * C::MOD[j] + t[j] + carry;
         t[j - 1] = (uint64_t)acc;
         carry = (uint64_t)(acc >> 64);
       }
-      acc = (u128)t[6] + carry;
-      t[5] = (uint64_t)acc;
-      t[6] = t[7] + (uint64_t)(acc >> 64);
+      acc = (u128)t[NW] + carry;
+      t[NW - 1] = (uint64_t)acc;
+      t[NW] = t[NW + 1] + (uint64_t)(acc >> 64);
     }
-    if (t[6] || geq_p(t)) sub_p(t);
+    if (t[NW] || geq_p(t)) sub_p(t);
     El r;
-    memcpy(r.v, t, 48);
+    memcpy(r.v, t, sizeof r.v);
     return r;
   }
   static El sqr(const El& a) { return mul(a, a); }
-  static El inv(const El& a) {  // a^(p-2)
+  static El inv(const El& a) {  // a^(p-2); p is odd and p = 1 mod 4 here, so only the low word changes
     El r = one();
-    for (int i = 383; i >= 0; i--) {
+    for (int i = 64 * NW - 1; i >= 0; i--) {
       r = sqr(r);
-      uint64_t w = C::MOD[i >> 6] - ((i >> 6) == 0 ? 2 : 0);  // p - 2: only the low word changes
+      uint64_t w = C::MOD[i >> 6] - ((i >> 6) == 0 ? 2 : 0);
       if ((w >> (i & 63)) & 1) r = mul(r, a);
     }
     return r;
   }
-  // 13 x 29-bit limbs, Montgomery radix 2^377 (the device format) -> this format.
+  // F29::N x 29-bit limbs in the device's Montgomery form -> this format.
   static El from_limbs29_mont(const uint32_t* l) {
-    uint32_t w[12];
-    Fp::El e;
-    for (int j = 0; j < 13; j++) e.l[j] = l[j];
-    Fp::to_words<12>(e, w);
-    El x, c;
-    for (int i = 0; i < 6; i++) {
-      x.v[i] = ((uint64_t)w[2 * i + 1] << 32) | w[2 * i];
-      c.v[i] = C::FROM29[i];
-    }
-    return mul(x, c);
+    uint32_t w[2 * NW];
+    typename F29::El e;
+    for (int j = 0; j < F29::N; j++) e.l[j] = l[j];
+    F29::template to_words<2 * NW>(e, w);
+    El x;
+    for (int i = 0; i < NW; i++) x.v[i] = ((uint64_t)w[2 * i + 1] << 32) | w[2 * i];
+    return mul(x, from_const(C::FROM29));
   }
-  // Montgomery -> canonical 48-byte little-endian.
+  // Montgomery -> canonical little-endian bytes (8 NW of them).
   static void to_wire(const El& a, uint8_t* out) {
     El o = zero();
     o.v[0] = 1;
     El t = mul(a, o);
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < NW; i++)
       for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(t.v[i] >> (8 * k));
   }
 };
 
+using Fp64 = FieldHost64<G1Consts64, Fp>;
+using Fq64 = FieldHost64<EdConsts64, Fq>;
+
+// ---- G1 tail ----
 using G1H = G1T<Fp64>;
 
 // X, Y, ZZ, ZZZ (13 device limbs each) -> host point.
@@ -185,6 +197,38 @@ inline void g1h_combine(const uint32_t* partials, uint8_t out[96]) {
     if (l == 0) acc = G1H::add(acc, g1h_from_device_words(base));
   }
   g1h_to_wire(acc, out);
+}
+
+// ---- Edwards tail ----
+struct EdK64 {
+  static Fq64::El two_d() { return Fq64::from_const(EdConsts64::ED_2D); }
+};
+using EdH = EdT<Fq64, EdK64>;
+
+inline EdH::Ext edh_from_device_words(const uint32_t* w36) {
+  EdH::Ext p;
+  p.x = Fq64::from_limbs29_mont(w36);
+  p.y = Fq64::from_limbs29_mont(w36 + 9);
+  p.t = Fq64::from_limbs29_mont(w36 + 18);
+  p.z = Fq64::from_limbs29_mont(w36 + 27);
+  return p;
+}
+inline void edh_to_wire(const EdH::Ext& p, uint8_t out[64]) {
+  Fq64::El zi = Fq64::inv(p.z);
+  Fq64::to_wire(Fq64::mul(p.x, zi), out);
+  Fq64::to_wire(Fq64::mul(p.y, zi), out + 32);
+}
+// Same Horner as g1h_combine; partials layout [window][point][36 words].
+inline void edh_combine(const uint32_t* partials, uint8_t out[64]) {
+  EdH::Ext acc = EdH::identity();
+  for (int b = 255; b >= 0; b--) {
+    acc = EdH::dbl(acc);
+    const int w = b >> 4, l = b & 15;
+    const uint32_t* base = partials + (size_t)w * 16 * 36;
+    if (l < 15) acc = EdH::add(acc, edh_from_device_words(base + (size_t)(1 + l) * 36));
+    if (l == 0) acc = EdH::add(acc, edh_from_device_words(base));
+  }
+  edh_to_wire(acc, out);
 }
 
 }  // namespace msm377

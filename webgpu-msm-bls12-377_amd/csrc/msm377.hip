@@ -62,59 +62,166 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ p, uin
   }
 }
 
-__device__ __forceinline__ G1Affine load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
-  uint32_t w[28];
-  load_words16(bases + (size_t)idx * REC_WORDS, w, 7);
-  G1Affine p;
+// ---- curve policies: what the curve-agnostic pipeline kernels need from a curve ----
+// Base = affine input point as kept in a 128-byte `bases` record; Pt = bucket point.
+struct G1Dev {
+  static constexpr uint32_t RAW_WORDS = 24;  // wire: x || y, 48 bytes each
+  static constexpr uint32_t PT_WORDS = 52;   // X, Y, ZZ, ZZZ
+  using Base = G1Affine;
+  using Pt = G1XYZZ;
+  static __device__ __forceinline__ void convert(const uint32_t* raw, uint32_t* rec) {
+    Fp::El x = Fp::to_mont(Fp::from_words<12>(raw));
+    Fp::El y = Fp::to_mont(Fp::from_words<12>(raw + 12));
 #pragma unroll
-  for (int j = 0; j < 13; j++) {
-    p.x.l[j] = w[j];
-    p.y.l[j] = w[13 + j];
+    for (int j = 0; j < 13; j++) {
+      rec[j] = x.l[j];
+      rec[13 + j] = y.l[j];
+    }
+#pragma unroll
+    for (int j = 26; j < 32; j++) rec[j] = 0;
   }
-  return p;
-}
+  static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
+    uint32_t w[28];
+    load_words16(bases + (size_t)idx * REC_WORDS, w, 7);
+    Base p;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      p.x.l[j] = w[j];
+      p.y.l[j] = w[13 + j];
+    }
+    return p;
+  }
+  static __device__ __forceinline__ Base cneg(const Base& p, bool c) {
+    Base r = p;
+    r.y = Fp::cneg(p.y, c);
+    return r;
+  }
+  static __device__ __forceinline__ Pt identity() { return G1::identity(); }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q) { return G1::madd(a, q); }
+  static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return G1::add(a, b); }
+  static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      w[j] = p.x.l[j];
+      w[13 + j] = p.y.l[j];
+      w[26 + j] = p.zz.l[j];
+      w[39 + j] = p.zzz.l[j];
+    }
+  }
+  static __device__ __forceinline__ Pt from_words(const uint32_t* w) {
+    Pt p;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      p.x.l[j] = w[j];
+      p.y.l[j] = w[13 + j];
+      p.zz.l[j] = w[26 + j];
+      p.zzz.l[j] = w[39 + j];
+    }
+    return p;
+  }
+};
 
-__device__ __forceinline__ G1XYZZ load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
-  const uint32_t* p = b + (size_t)ws * PT_WORDS * NB + t;
-  G1XYZZ r;
+struct EdDev {
+  static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
+  static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
+  using Base = Ed::Base;
+  using Pt = Ed::Ext;
+  // record: (y - x)[9] (y + x)[9] (2d x y)[9] pad[5]
+  static __device__ __forceinline__ void convert(const uint32_t* raw, uint32_t* rec) {
+    Fq::El x = Fq::to_mont(Fq::from_words<8>(raw));
+    Fq::El y = Fq::to_mont(Fq::from_words<8>(raw + 8));
+    Base b = Ed::make_base(x, y);
 #pragma unroll
-  for (int j = 0; j < 13; j++) {
-    r.x.l[j] = p[(size_t)j * NB];
-    r.y.l[j] = p[(size_t)(13 + j) * NB];
-    r.zz.l[j] = p[(size_t)(26 + j) * NB];
-    r.zzz.l[j] = p[(size_t)(39 + j) * NB];
+    for (int j = 0; j < 9; j++) {
+      rec[j] = b.ymx.l[j];
+      rec[9 + j] = b.ypx.l[j];
+      rec[18 + j] = b.kt.l[j];
+    }
+#pragma unroll
+    for (int j = 27; j < 32; j++) rec[j] = 0;
   }
-  return r;
+  static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
+    uint32_t w[28];
+    load_words16(bases + (size_t)idx * REC_WORDS, w, 7);
+    Base p;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      p.ymx.l[j] = w[j];
+      p.ypx.l[j] = w[9 + j];
+      p.kt.l[j] = w[18 + j];
+    }
+    return p;
+  }
+  static __device__ __forceinline__ Base cneg(const Base& p, bool c) { return Ed::cneg(p, c); }
+  static __device__ __forceinline__ Pt identity() { return Ed::identity(); }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q) { return Ed::madd(a, q); }
+  static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return Ed::add(a, b); }
+  static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      w[j] = p.x.l[j];
+      w[9 + j] = p.y.l[j];
+      w[18 + j] = p.t.l[j];
+      w[27 + j] = p.z.l[j];
+    }
+  }
+  static __device__ __forceinline__ Pt from_words(const uint32_t* w) {
+    Pt p;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      p.x.l[j] = w[j];
+      p.y.l[j] = w[9 + j];
+      p.t.l[j] = w[18 + j];
+      p.z.l[j] = w[27 + j];
+    }
+    return p;
+  }
+};
+
+// Limb-major bucket array: word j of bucket t of window slot ws at [(ws * PT_WORDS + j) * NB + t].
+template <class CV>
+__device__ __forceinline__ typename CV::Pt load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
+  const uint32_t* p = b + (size_t)ws * CV::PT_WORDS * NB + t;
+  uint32_t w[CV::PT_WORDS];
+#pragma unroll
+  for (uint32_t j = 0; j < CV::PT_WORDS; j++) w[j] = p[(size_t)j * NB];
+  return CV::from_words(w);
 }
-__device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t ws, uint32_t t, const G1XYZZ& r) {
-  uint32_t* p = b + (size_t)ws * PT_WORDS * NB + t;
+template <class CV>
+__device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t ws, uint32_t t, const typename CV::Pt& r) {
+  uint32_t* p = b + (size_t)ws * CV::PT_WORDS * NB + t;
+  uint32_t w[CV::PT_WORDS];
+  CV::to_words(r, w);
 #pragma unroll
-  for (int j = 0; j < 13; j++) {
-    p[(size_t)j * NB] = r.x.l[j];
-    p[(size_t)(13 + j) * NB] = r.y.l[j];
-    p[(size_t)(26 + j) * NB] = r.zz.l[j];
-    p[(size_t)(39 + j) * NB] = r.zzz.l[j];
-  }
+  for (uint32_t j = 0; j < CV::PT_WORDS; j++) p[(size_t)j * NB] = w[j];
+}
+// Point-major ("AoS") copy for the overflow partials: PT_WORDS is a multiple of 4.
+template <class CV>
+__device__ __forceinline__ void store_point_aos(uint32_t* __restrict__ dst, const typename CV::Pt& r) {
+  uint32_t w[CV::PT_WORDS];
+  CV::to_words(r, w);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+  for (uint32_t q = 0; q < CV::PT_WORDS / 4; q++) d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+template <class CV>
+__device__ __forceinline__ typename CV::Pt load_point_aos(const uint32_t* __restrict__ src) {
+  uint32_t w[CV::PT_WORDS];
+  load_words16(src, w, CV::PT_WORDS / 4);
+  return CV::from_words(w);
 }
 
 // ------------------------------------------------------------------------ kernels ----
 
-// One thread per point: 96-byte wire record -> 128-byte Montgomery record.
+// One thread per point: wire record (96 bytes G1, 64 bytes Edwards) -> 128-byte Montgomery record.
+template <class CV>
 __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint32_t w[24];
-  load_words16(raw + i * 24, w, 6);
-  Fp::El x = Fp::to_mont(Fp::from_words<12>(w));
-  Fp::El y = Fp::to_mont(Fp::from_words<12>(w + 12));
-  uint32_t o[32];
-#pragma unroll
-  for (int j = 0; j < 13; j++) {
-    o[j] = x.l[j];
-    o[13 + j] = y.l[j];
-  }
-#pragma unroll
-  for (int j = 26; j < 32; j++) o[j] = 0;
+  uint32_t w[CV::RAW_WORDS];
+  load_words16(raw + i * CV::RAW_WORDS, w, CV::RAW_WORDS / 4);
+  uint32_t o[REC_WORDS];
+  CV::convert(w, o);
   uint4* dst = reinterpret_cast<uint4*>(bases + i * REC_WORDS);
 #pragma unroll
   for (int k = 0; k < 8; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
@@ -327,6 +434,7 @@ __global__ void __launch_bounds__(256) k_work_scatter(const uint32_t* __restrict
 
 // One thread per work item.  The next record is requested before the current mixed addition
 // so the gather latency hides under ~10 field multiplications.
+template <class CV>
 __global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
@@ -340,43 +448,33 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restric
   const uint32_t row_end = rp[t + 2];
   uint32_t k = rp[t + 1] + it.seg * SEG;
   const uint32_t end = (row_end - k > SEG) ? k + SEG : row_end;
-  G1XYZZ acc = g1_identity();
+  typename CV::Pt acc = CV::identity();
   if (k < end) {
     uint32_t e = vi[k];
-    G1Affine p = load_base(bases, e & 0x7fffffffu);
+    typename CV::Base p = CV::load_base(bases, e & 0x7fffffffu);
     while (true) {
       const uint32_t e_cur = e;
-      G1Affine cur = p;
+      const typename CV::Base cur = p;
       k++;
       const bool more = k < end;
       if (more) {
         e = vi[k];
-        p = load_base(bases, e & 0x7fffffffu);
+        p = CV::load_base(bases, e & 0x7fffffffu);
       }
-      cur.y = Fp::cneg(cur.y, (e_cur >> 31) != 0);
-      acc = g1_madd(acc, cur);
+      acc = CV::madd(acc, CV::cneg(cur, (e_cur >> 31) != 0));
       if (!more) break;
     }
   }
   if (it.seg == 0) {
-    store_bucket(buckets, ws, t, acc);
+    store_bucket<CV>(buckets, ws, t, acc);
   } else {
-    uint4* d = reinterpret_cast<uint4*>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * PT_WORDS);
-    uint32_t w[PT_WORDS];
-#pragma unroll
-    for (int j = 0; j < 13; j++) {
-      w[j] = acc.x.l[j];
-      w[13 + j] = acc.y.l[j];
-      w[26 + j] = acc.zz.l[j];
-      w[39 + j] = acc.zzz.l[j];
-    }
-#pragma unroll
-    for (int q = 0; q < 13; q++) d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    store_point_aos<CV>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * CV::PT_WORDS, acc);
   }
 }
 
 // Thread per split row: bucket += its overflow partials (serial; 3 additions per row of the
 // top window at n = 2^20, more only under heavy skew).
+template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
                                                              const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf) {
@@ -386,22 +484,10 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
     const uint32_t len = row_len(row_ptr, row);
     const uint32_t nseg = (len + SEG - 1) / SEG;
     const uint32_t ws = row / NB, t = row % NB;
-    G1XYZZ acc = load_bucket(buckets, ws, t);
-    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * PT_WORDS;
-    for (uint32_t s = 1; s < nseg; s++) {
-      uint32_t w[PT_WORDS];
-      load_words16(src + (size_t)(s - 1) * PT_WORDS, w, 13);
-      G1XYZZ o;
-#pragma unroll
-      for (int j = 0; j < 13; j++) {
-        o.x.l[j] = w[j];
-        o.y.l[j] = w[13 + j];
-        o.zz.l[j] = w[26 + j];
-        o.zzz.l[j] = w[39 + j];
-      }
-      acc = g1_add(acc, o);
-    }
-    store_bucket(buckets, ws, t, acc);
+    typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
+    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::PT_WORDS;
+    for (uint32_t s = 1; s < nseg; s++) acc = CV::add(acc, load_point_aos<CV>(src + (size_t)(s - 1) * CV::PT_WORDS));
+    store_bucket<CV>(buckets, ws, t, acc);
   }
 }
 
@@ -424,35 +510,38 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
 //     S = sum_j B_j -> B[k],   bit 14: B4+..+B7 -> B[NB/2 + k],
 //     bit 13: B2+B3+B6+B7 -> B[NB/4 + k],   bit 12: B1+B3+B5+B7 -> B[NB/8 + k]
 // with 11 additions (one wave per SIMD: it needs ~6 live points).
+template <class CV>
 __global__ void __launch_bounds__(256, 1) k_reduce_first(uint32_t* __restrict__ buckets) {
+  using Pt = typename CV::Pt;
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // < NB / 8
   const uint32_t ws = blockIdx.y;
   constexpr uint32_t Q = NB / 8;
-  G1XYZZ b0 = load_bucket(buckets, ws, k);
-  G1XYZZ b1 = load_bucket(buckets, ws, k + Q);
-  G1XYZZ s0123 = g1_add(b0, b1);
-  G1XYZZ p12 = b1;
-  G1XYZZ b2 = load_bucket(buckets, ws, k + 2 * Q);
-  G1XYZZ b3 = load_bucket(buckets, ws, k + 3 * Q);
-  G1XYZZ s23 = g1_add(b2, b3);
-  p12 = g1_add(p12, b3);
-  s0123 = g1_add(s0123, s23);
-  G1XYZZ b4 = load_bucket(buckets, ws, k + 4 * Q);
-  G1XYZZ b5 = load_bucket(buckets, ws, k + 5 * Q);
-  G1XYZZ s4567 = g1_add(b4, b5);
-  p12 = g1_add(p12, b5);
-  G1XYZZ b6 = load_bucket(buckets, ws, k + 6 * Q);
-  G1XYZZ b7 = load_bucket(buckets, ws, k + 7 * Q);
-  G1XYZZ s67 = g1_add(b6, b7);
-  p12 = g1_add(p12, b7);
-  store_bucket(buckets, ws, k + Q, p12);
-  store_bucket(buckets, ws, k + 2 * Q, g1_add(s23, s67));
-  s4567 = g1_add(s4567, s67);
-  store_bucket(buckets, ws, k + 4 * Q, s4567);
-  store_bucket(buckets, ws, k, g1_add(s0123, s4567));
+  Pt b0 = load_bucket<CV>(buckets, ws, k);
+  Pt b1 = load_bucket<CV>(buckets, ws, k + Q);
+  Pt s0123 = CV::add(b0, b1);
+  Pt p12 = b1;
+  Pt b2 = load_bucket<CV>(buckets, ws, k + 2 * Q);
+  Pt b3 = load_bucket<CV>(buckets, ws, k + 3 * Q);
+  Pt s23 = CV::add(b2, b3);
+  p12 = CV::add(p12, b3);
+  s0123 = CV::add(s0123, s23);
+  Pt b4 = load_bucket<CV>(buckets, ws, k + 4 * Q);
+  Pt b5 = load_bucket<CV>(buckets, ws, k + 5 * Q);
+  Pt s4567 = CV::add(b4, b5);
+  p12 = CV::add(p12, b5);
+  Pt b6 = load_bucket<CV>(buckets, ws, k + 6 * Q);
+  Pt b7 = load_bucket<CV>(buckets, ws, k + 7 * Q);
+  Pt s67 = CV::add(b6, b7);
+  p12 = CV::add(p12, b7);
+  store_bucket<CV>(buckets, ws, k + Q, p12);
+  store_bucket<CV>(buckets, ws, k + 2 * Q, CV::add(s23, s67));
+  s4567 = CV::add(s4567, s67);
+  store_bucket<CV>(buckets, ws, k + 4 * Q, s4567);
+  store_bucket<CV>(buckets, ws, k, CV::add(s0123, s4567));
 }
 
 // One level r >= 3 of the reduction (see above): (r + 1) lists of NB/2^(r+1) pair-additions.
+template <class CV>
 __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   const uint32_t ws = blockIdx.y;
@@ -462,17 +551,17 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);  // list of level r' = oi - 1 starts at NB/2^(r'+1)
   const uint32_t x = lo + kk;
   const uint32_t y = x + half;
-  G1XYZZ a = load_bucket(buckets, ws, x);
-  G1XYZZ b = load_bucket(buckets, ws, y);
-  store_bucket(buckets, ws, x, g1_add(a, b));
+  typename CV::Pt a = load_bucket<CV>(buckets, ws, x);
+  typename CV::Pt b = load_bucket<CV>(buckets, ws, y);
+  store_bucket<CV>(buckets, ws, x, CV::add(a, b));
 }
 
 // Pack the 16 partial points of every window slot: point 0 = B[0], point 1 + l = B[2^l].
-__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t pt_words) {
   const uint32_t ws = blockIdx.x, pt = blockIdx.y, j = threadIdx.x;
-  if (j >= PT_WORDS) return;
+  if (j >= pt_words) return;
   const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
-  out[((size_t)ws * MSM377_G1_PARTIAL_POINTS + pt) * PT_WORDS + j] = buckets[((size_t)ws * PT_WORDS + j) * NB + x];
+  out[((size_t)ws * MSM377_G1_PARTIAL_POINTS + pt) * pt_words + j] = buckets[((size_t)ws * pt_words + j) * NB + x];
 }
 
 // Synthetic bases: P_i = [a_i]G with a_i the (i+1)-th SplitMix64(seed) output, wire format.
@@ -514,6 +603,35 @@ __global__ void __launch_bounds__(256, 2) k_generate_bases(uint64_t seed, uint64
   for (int k = 0; k < 6; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 
+// Edwards twin: P_i = [a_i]G_ed (generator: src/reference/utils/FieldMath.ts:108-109), 64-byte wire records.
+__global__ void __launch_bounds__(256, 2) k_generate_bases_ed(uint64_t seed, uint64_t n, uint32_t* __restrict__ out_raw) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t a = splitmix64_at(seed, i);
+  if (a == 0) a = 1;
+  const Ed::Base gen = Ed::make_base(Fq::from_const(EdConsts::GEN_X), Fq::from_const(EdConsts::GEN_Y));
+  Ed::Ext acc = Ed::identity();
+#pragma unroll 1
+  for (int bit = 63; bit >= 0; bit--) {
+    acc = Ed::dbl(acc);
+    if ((a >> bit) & 1) acc = Ed::madd(acc, gen);
+  }
+  Fq::El zi = Fq::one();
+#pragma unroll 1
+  for (int b = EdConsts::PM2_NW * 32 - 1; b >= 0; b--) {
+    zi = Fq::sqr(zi);
+    if ((EdConsts::PM2_W[b >> 5] >> (b & 31)) & 1u) zi = Fq::mul(zi, acc.z);
+  }
+  Fq::El x = Fq::from_mont(Fq::mul(acc.x, zi));
+  Fq::El y = Fq::from_mont(Fq::mul(acc.y, zi));
+  uint32_t w[16];
+  Fq::to_words<8>(x, w);
+  Fq::to_words<8>(y, w + 8);
+  uint4* dst = reinterpret_cast<uint4*>(out_raw + i * 16);
+#pragma unroll
+  for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------- context ----
@@ -548,6 +666,7 @@ struct msm377_ctx {
   uint64_t bases_n = 0;  // resident base count (fixed-base mode)
   uint64_t last_n = 0;
   uint32_t last_wc = 0;
+  bool last_is_g1 = false;
   bool capture = false;
   bool timing = false;
   hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
@@ -582,16 +701,18 @@ struct StageTimer {
   }
 };
 
+template <class CV>
 int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
   StageTimer t(ctx, MSM377_STAGE_CONVERT);
   if (n == 0) return MSM377_OK;
-  hipLaunchKernelGGL(k_convert_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, ctx->d_bases, n);
+  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, ctx->d_bases, n);
   HIP_TRY(ctx, hipGetLastError());
   return MSM377_OK;
 }
 
 // Stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases; leaves the
-// partial records in ctx->h_partials (wc x 16 x 52 words) and synchronises the stream.
+// partial records in ctx->h_partials (wc x 16 x PT_WORDS words) and synchronises the stream.
+template <class CV>
 int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc) {
   hipStream_t st = ctx->stream;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), st));
@@ -634,33 +755,34 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
     hipLaunchKernelGGL(k_work_scatter, dim3(rows / 256), dim3(256), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx, ctx->d_bases,
+    hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx, ctx->d_bases,
                        ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_merge_split_rows, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters, ctx->d_split_rows,
+    hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters, ctx->d_split_rows,
                        ctx->d_row_ovf_base, ctx->d_ovf);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->capture) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, ctx->d_buckets, (size_t)wc * PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, ctx->d_buckets, (size_t)wc * CV::PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
   }
   {
     StageTimer t(ctx, MSM377_STAGE_REDUCE);
-    hipLaunchKernelGGL(k_reduce_first, dim3(NB / 8 / 256, wc), dim3(256), 0, st, ctx->d_buckets);
+    hipLaunchKernelGGL(k_reduce_first<CV>, dim3(NB / 8 / 256, wc), dim3(256), 0, st, ctx->d_buckets);
     HIP_TRY(ctx, hipGetLastError());
     for (uint32_t r = 3; r < TREE_LEVELS; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
-      hipLaunchKernelGGL(k_tree_step, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
+      hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_gather_partials, dim3(wc, MSM377_G1_PARTIAL_POINTS), dim3(64), 0, st, ctx->d_buckets, ctx->d_partials);
+    hipLaunchKernelGGL(k_gather_partials, dim3(wc, MSM377_G1_PARTIAL_POINTS), dim3(64), 0, st, ctx->d_buckets, ctx->d_partials, CV::PT_WORDS);
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials, (size_t)wc * MSM377_G1_WINDOW_PARTIAL_BYTES, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::PT_WORDS * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   ctx->last_n = n;
   ctx->last_wc = wc;
+  ctx->last_is_g1 = CV::PT_WORDS == G1Dev::PT_WORDS;
   if (ctx->timing) {
     for (int s = 0; s < MSM377_STAGE_TAIL; s++) {
       float ms = 0.f;
@@ -791,9 +913,9 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
-  rc = convert_bases(ctx, (const uint32_t*)d_points, n);
+  rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
-  rc = run_windows(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
   if (rc) return rc;
   return finish_full(ctx, out_xy);
 }
@@ -815,11 +937,57 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
   return msm377_g1_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
 }
 
+// ---- Edwards-BLS12 (BASELINE.json config 3): same pipeline, EdDev policy ----
+int msm377_ed_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[64]) {
+  if (!out_xy) return MSM377_EINVAL;
+  int rc = check_args(ctx, d_points, d_scalars, n, true);
+  if (rc) return rc;
+  if (n == 0) {  // the neutral element (0, 1)
+    memset(out_xy, 0, 64);
+    out_xy[32] = 1;
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->bases_n = 0;
+  rc = convert_bases<EdDev>(ctx, (const uint32_t*)d_points, n);
+  if (rc) return rc;
+  rc = run_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  if (rc) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  edh_combine(ctx->h_partials, out_xy);
+  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MSM377_OK;
+}
+
+int msm377_ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[64]) {
+  if (!ctx || !out_xy) return MSM377_EINVAL;
+  ctx->err.clear();
+  if (n > ctx->cap || (n && (!points || !scalars))) {
+    ctx->err = "bad arguments";
+    return MSM377_EINVAL;
+  }
+  if (n == 0) return msm377_ed_msm_device(ctx, nullptr, nullptr, 0, out_xy);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, points, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_scalars, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return msm377_ed_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
+}
+
+int msm377_ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out) {
+  if (!ctx || (n && !d_points_out) || ((uintptr_t)d_points_out & 15)) return MSM377_EINVAL;
+  if (n == 0) return MSM377_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_generate_bases_ed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, n, (uint32_t*)d_points_out);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM377_OK;
+}
+
 int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  rc = convert_bases(ctx, (const uint32_t*)d_points, n);
+  rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->bases_n = n;
@@ -850,7 +1018,7 @@ int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint
     (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream);
     (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream);
   }
-  rc = run_windows(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
   if (rc) return rc;
   return finish_full(ctx, out_xy);
 }
@@ -877,9 +1045,9 @@ int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, cons
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
-  rc = convert_bases(ctx, (const uint32_t*)d_points, n);
+  rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
-  rc = run_windows(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count);
+  rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count);
   if (rc) return rc;
   memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
   return MSM377_OK;
@@ -913,7 +1081,7 @@ int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled) {
 
 int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint32_t* row_ptr, uint32_t* val_idx, uint32_t* buckets) {
   if (!ctx) return MSM377_EINVAL;
-  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc) {
+  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc || !ctx->last_is_g1) {
     ctx->err = "no captured stage data for that window slot";
     return MSM377_ESTATE;
   }

@@ -68,6 +68,9 @@ def load_library():
         "msm377_g1_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_combine_partials": (i32, [vp, vp]),
         "msm377_g1_generate_bases_device": (i32, [vp, u64, u64, vp]),
+        "msm377_ed_msm": (i32, [vp, u8p, u8p, u64, vp]),
+        "msm377_ed_msm_device": (i32, [vp, vp, vp, u64, vp]),
+        "msm377_ed_generate_bases_device": (i32, [vp, u64, u64, vp]),
         "msm377_ctx_set_stage_capture": (i32, [vp, i32]),
         "msm377_g1_read_stage": (i32, [vp, u32, vp, vp, vp, vp]),
         "msm377_g1_xyzz_to_affine": (i32, [vp, vp]),
@@ -196,6 +199,22 @@ class MsmEngine:
 
     def generate_bases_device(self, seed: int, n: int, d_points_out: int):
         self._check(self._lib.msm377_g1_generate_bases_device(self._ctx, int(seed) & (2**64 - 1), int(n), d_points_out), "msm377_g1_generate_bases_device")
+
+    # -- Twisted-Edwards BLS12 (BASELINE.json config 3): 64-byte points, 64-byte result --
+    def ed_msm(self, points: bytes, scalars: bytes) -> bytes:
+        if len(scalars) % 32 or len(points) != 2 * len(scalars):
+            raise ValueError("Edwards points buffer must hold 64 bytes and scalars 32 bytes per input")
+        out = ctypes.create_string_buffer(64)
+        self._check(self._lib.msm377_ed_msm(self._ctx, bytes(points), bytes(scalars), len(scalars) // 32, ctypes.addressof(out)), "msm377_ed_msm")
+        return out.raw
+
+    def ed_msm_device(self, d_points: int, d_scalars: int, n: int) -> bytes:
+        out = ctypes.create_string_buffer(64)
+        self._check(self._lib.msm377_ed_msm_device(self._ctx, d_points, d_scalars, int(n), ctypes.addressof(out)), "msm377_ed_msm_device")
+        return out.raw
+
+    def ed_generate_bases_device(self, seed: int, n: int, d_points_out: int):
+        self._check(self._lib.msm377_ed_generate_bases_device(self._ctx, int(seed) & (2**64 - 1), int(n), d_points_out), "msm377_ed_generate_bases_device")
 
     # -- stage access (the reference's debug=true read-backs) --
     def set_stage_capture(self, enabled: bool = True):
