@@ -253,6 +253,13 @@ __device__ __forceinline__ void digit_key(uint32_t biased, uint32_t& key, uint32
   key = (uint32_t)(d < 0 ? -d : d);
 }
 
+// ---- per-window counting sort (the reference's transpose, transpose_serial.wgsl:34-76) ----
+// One 131 KB LDS histogram per CU: block (chunk c, window slot ws) counts its chunk's keys
+// (k_hist), k_chunk_prefix turns the per-chunk counts into exclusive prefixes, k_scan_totals
+// scans the 32769 key totals into row_ptr, and k_scatter re-reads the chunk and hands every
+// element its slot with one LDS atomic.  (A key-range-partitioned variant with contiguous
+// output slices was measured slower: every block then filters the whole digit column.)
+
 // Block (chunk c, window slot ws): histogram of the chunk's keys in LDS (131 KB), written
 // out as hist_chunk[ws][c][key].
 __global__ void __launch_bounds__(1024) k_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ hist_chunk, uint64_t n,
@@ -288,35 +295,43 @@ __global__ void __launch_bounds__(256) k_chunk_prefix(uint32_t* __restrict__ his
   tot[(size_t)ws * NBIN + k] = run;
 }
 
-// Block per window slot: row_ptr = exclusive scan of the 32769 key totals.
+// Block per window slot: row_ptr = exclusive scan of the 32769 key counts.  The counts are
+// staged in LDS so that global access is unit-stride while each thread scans 33 consecutive
+// entries (LDS stride 33 words: conflict-free).
 __global__ void __launch_bounds__(1024) k_scan_totals(const uint32_t* __restrict__ tot, uint32_t* __restrict__ row_ptr) {
-  __shared__ uint32_t part[1024];
+  extern __shared__ uint32_t lds[];  // NBIN counts, then 1024 partials
+  uint32_t* part = lds + NBIN;
   const uint32_t ws = blockIdx.x, tid = threadIdx.x;
   const uint32_t* t = tot + (size_t)ws * NBIN;
   uint32_t* rp = row_ptr + (size_t)ws * RP;
   constexpr uint32_t PER = (NBIN + 1023) / 1024;  // 33
+  for (uint32_t k = tid; k < NBIN; k += 1024) lds[k] = t[k];
+  __syncthreads();
   const uint32_t base = tid * PER;
   uint32_t s = 0;
   for (uint32_t j = 0; j < PER; j++) {
-    uint32_t k = base + j;
-    if (k < NBIN) s += t[k];
+    const uint32_t k = base + j;
+    if (k < NBIN) s += lds[k];
   }
   part[tid] = s;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t v = tid >= off ? part[tid - off] : 0;
+    const uint32_t v = tid >= off ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
   uint32_t run = part[tid] - s;
   for (uint32_t j = 0; j < PER; j++) {
-    uint32_t k = base + j;
+    const uint32_t k = base + j;
     if (k < NBIN) {
-      rp[k] = run;
-      run += t[k];
+      const uint32_t c = lds[k];
+      lds[k] = run;
+      run += c;
     }
   }
+  __syncthreads();
+  for (uint32_t k = tid; k < NBIN; k += 1024) rp[k] = lds[k];
   if (tid == 1023) rp[NBIN] = part[1023];
 }
 
@@ -432,8 +447,7 @@ __global__ void __launch_bounds__(256) k_work_scatter(const uint32_t* __restrict
   }
 }
 
-// One thread per work item.  The next record is requested before the current mixed addition
-// so the gather latency hides under ~10 field multiplications.
+// One thread per work item.
 template <class CV>
 __global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
@@ -450,19 +464,26 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restric
   const uint32_t end = (row_end - k > SEG) ? k + SEG : row_end;
   typename CV::Pt acc = CV::identity();
   if (k < end) {
-    uint32_t e = vi[k];
-    typename CV::Base p = CV::load_base(bases, e & 0x7fffffffu);
+    // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
+    // entry k is added, so neither the val_idx -> bases address dependency nor the gather
+    // latency stalls the wave.
+    uint32_t e_cur = vi[k];
+    uint32_t e_nxt = (k + 1 < end) ? vi[k + 1] : 0u;
+    typename CV::Base cur = CV::load_base(bases, e_cur & 0x7fffffffu);
     while (true) {
-      const uint32_t e_cur = e;
-      const typename CV::Base cur = p;
       k++;
       const bool more = k < end;
+      typename CV::Base nxt = cur;
+      uint32_t e_nn = 0u;
       if (more) {
-        e = vi[k];
-        p = CV::load_base(bases, e & 0x7fffffffu);
+        nxt = CV::load_base(bases, e_nxt & 0x7fffffffu);
+        if (k + 1 < end) e_nn = vi[k + 1];
       }
       acc = CV::madd(acc, CV::cneg(cur, (e_cur >> 31) != 0));
       if (!more) break;
+      cur = nxt;
+      e_cur = e_nxt;
+      e_nxt = e_nn;
     }
   }
   if (it.seg == 0) {
@@ -669,6 +690,7 @@ struct msm377_ctx {
   bool last_is_g1 = false;
   bool capture = false;
   bool timing = false;
+  bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
   hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
   double stage_ms[MSM377_NUM_STAGES] = {};
 };
@@ -732,7 +754,7 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_chunk_prefix, dim3((NBIN + 255) / 256, wc), dim3(256), 0, st, ctx->d_hist_chunk, ctx->d_tot, chunks);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_totals, dim3(wc), dim3(1024), 0, st, ctx->d_tot, ctx->d_row_ptr);
+    hipLaunchKernelGGL(k_scan_totals, dim3(wc), dim3(1024), (NBIN + 1024) * sizeof(uint32_t), st, ctx->d_tot, ctx->d_row_ptr);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_scatter, dim3(chunks, wc), dim3(1024), lds_bytes, st, ctx->d_digits, ctx->d_hist_chunk, ctx->d_row_ptr,
                        ctx->d_val_idx, n, chunks, per_chunk);
@@ -767,9 +789,13 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
   }
   {
     StageTimer t(ctx, MSM377_STAGE_REDUCE);
-    hipLaunchKernelGGL(k_reduce_first<CV>, dim3(NB / 8 / 256, wc), dim3(256), 0, st, ctx->d_buckets);
-    HIP_TRY(ctx, hipGetLastError());
-    for (uint32_t r = 3; r < TREE_LEVELS; r++) {
+    uint32_t first_level = 0;
+    if (ctx->reduce_fused) {
+      hipLaunchKernelGGL(k_reduce_first<CV>, dim3(NB / 8 / 256, wc), dim3(256), 0, st, ctx->d_buckets);
+      HIP_TRY(ctx, hipGetLastError());
+      first_level = 3;
+    }
+    for (uint32_t r = first_level; r < TREE_LEVELS; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
       HIP_TRY(ctx, hipGetLastError());
@@ -850,6 +876,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (!ctx) return MSM377_ENOMEM;
   ctx->device = device;
   ctx->cap = max_points;
+  if (const char* e = getenv("MSM377_REDUCE_FUSED")) ctx->reduce_fused = atoi(e) != 0;
   const uint64_t cap = max_points;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
@@ -876,6 +903,8 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   const size_t lds_bytes = NBIN * sizeof(uint32_t);
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_totals), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((NBIN + 1024) * sizeof(uint32_t))) == hipSuccess;
   if (!ok) {
     msm377_ctx_destroy(ctx);
     return MSM377_ENOMEM;
