@@ -77,7 +77,7 @@ def main():
     import torch
 
     import webgpu_msm_bls12_377_amd as msm
-    from webgpu_msm_bls12_377_amd.host.sharding import sharded_msm, windows_for_rank
+    from webgpu_msm_bls12_377_amd.host.sharding import ShardedMsm, windows_for_rank
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,13 +86,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Rehearsal knobs for a one-GPU box (never set by the driver): MSM377_BENCH_SINGLE_DEVICE=1 puts every
+    # rank on device 0 and MSM377_BENCH_BACKEND=gloo moves the gather to CPU tensors -- RCCL refuses two ranks
+    # on one device.  The default is one rank per GPU over RCCL ("nccl").
+    if os.environ.get("MSM377_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MSM377_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = 1 << args.log_n
     eng = msm.MsmEngine(n, device=local_rank)
@@ -103,11 +112,13 @@ def main():
     torch.cuda.synchronize()
     pp, sp = d_points.data_ptr(), d_scalars.data_ptr()
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where the exchange buffers live
+    sharder = ShardedMsm(rank, world, device=xdev)
 
     def step():
         if world == 1:
             return eng.msm_device(pp, sp, n)
-        return sharded_msm(lambda b, c: eng.window_partials_device(pp, sp, n, b, c), rank, world, device=dev)
+        return sharder.run(lambda b, c: eng.window_partials_device(pp, sp, n, b, c))
 
     def fence():
         if dist is not None:
@@ -129,7 +140,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.set_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -139,7 +150,7 @@ def main():
     if rank == 0:
         whole_bytes, acc_bytes = algorithmic_bytes(n)
         _, my_windows = windows_for_rank(rank, world)
-        acc_ms = stages.get("accumulate", 0.0)
+        acc_ms = stages.get("accumulate_kernel", 0.0)  # HIP events around the k_accumulate launch alone
         acc_bytes_launch = acc_bytes * my_windows / NUM_WINDOWS  # one launch covers this rank's windows
         achieved = acc_bytes_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         out = {

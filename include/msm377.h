@@ -129,7 +129,9 @@ int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
 #define MSM377_STAGE_ACCUMULATE 3  /* bucket accumulation (SMVP) -- the dominant kernel */
 #define MSM377_STAGE_REDUCE 4      /* bucket reduction tree */
 #define MSM377_STAGE_TAIL 5        /* D2H of the partial records + host Horner/inversion */
-#define MSM377_NUM_STAGES 6
+#define MSM377_STAGE_ACC_KERNEL 6  /* the k_accumulate launch alone (inside STAGE_ACCUMULATE, which also
+                                      covers the work-list kernels and the split-row merge) */
+#define MSM377_NUM_STAGES 7
 /* Enable HIP-event timing of every stage on the context's stream (off by default). */
 int msm377_ctx_set_timing(msm377_ctx* ctx, int enabled);
 /* Durations in milliseconds of the last call's stages (MSM377_NUM_STAGES entries; the TAIL

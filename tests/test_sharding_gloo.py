@@ -43,7 +43,12 @@ def _worker(rank, world, port, case_name, q):
             return b"".join(util.partial_record_from_window_sum(R.decode_result(ws[96 * w : 96 * w + 96])) for w in range(begin, begin + count))
 
         out = sharded_msm(partials_fn, rank, world, device="cpu")
-        q.put((rank, out == case["expected"]))
+        from webgpu_msm_bls12_377_amd.host.sharding import ShardedMsm
+
+        sh = ShardedMsm(rank, world, device="cpu")
+        out2 = sh.run(partials_fn)
+        out3 = sh.run(partials_fn)  # buffers are reusable
+        q.put((rank, out == case["expected"] and out2 == out and out3 == out))
     finally:
         dist.destroy_process_group()
 

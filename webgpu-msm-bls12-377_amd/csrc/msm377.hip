@@ -777,8 +777,11 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
     hipLaunchKernelGGL(k_work_scatter, dim3(rows / 256), dim3(256), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
-    hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx, ctx->d_bases,
-                       ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+    {
+      StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
+      hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
+                         ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+    }
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters, ctx->d_split_rows,
                        ctx->d_row_ovf_base, ctx->d_ovf);
@@ -810,7 +813,8 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
   ctx->last_wc = wc;
   ctx->last_is_g1 = CV::PT_WORDS == G1Dev::PT_WORDS;
   if (ctx->timing) {
-    for (int s = 0; s < MSM377_STAGE_TAIL; s++) {
+    for (int s = 0; s < MSM377_NUM_STAGES; s++) {
+      if (s == MSM377_STAGE_TAIL) continue;  // host wall time, set by the caller
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->ev[s][0], ctx->ev[s][1]) == hipSuccess) ctx->stage_ms[s] = ms;
     }

@@ -16,7 +16,7 @@ PARTIAL_POINTS = 16
 POINT_WORDS = 52
 WINDOW_PARTIAL_BYTES = PARTIAL_POINTS * POINT_WORDS * 4
 NUM_BUCKETS = 32768
-STAGE_NAMES = ("convert", "decompose", "sort", "accumulate", "reduce", "tail")
+STAGE_NAMES = ("convert", "decompose", "sort", "accumulate", "reduce", "tail", "accumulate_kernel")
 
 OK, EINVAL, EHIP, ESCALAR, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 

@@ -28,6 +28,44 @@ def combine_partials(partials: bytes) -> bytes:
     return combine_partials_bytes(partials)
 
 
+class ShardedMsm:
+    """sharded_msm with the exchange buffers allocated once (bench.py, services): a pinned host
+    staging tensor, a send tensor and a world_size-slot receive tensor on ``device``."""
+
+    def __init__(self, rank: int, world_size: int, group=None, device=None):
+        import torch
+
+        self.rank, self.world, self.group = rank, world_size, group
+        self.begin, self.count = windows_for_rank(rank, world_size)
+        self.max_count = (NUM_WINDOWS + world_size - 1) // world_size
+        self.slot = self.max_count * WINDOW_PARTIAL_BYTES
+        self.counts = [windows_for_rank(r, world_size)[1] for r in range(world_size)]
+        if world_size > 1:
+            pin = device is not None and str(device).startswith("cuda")
+            self.send_host = torch.zeros(self.slot, dtype=torch.uint8, pin_memory=pin)
+            self.recv_host = torch.zeros(self.slot * world_size, dtype=torch.uint8, pin_memory=pin)
+            dev = device if device is not None else "cpu"
+            self.send_dev = torch.zeros(self.slot, dtype=torch.uint8, device=dev)
+            self.recv_dev = torch.zeros(self.slot * world_size, dtype=torch.uint8, device=dev)
+
+    def run(self, partials_fn: Callable[[int, int], bytes]) -> bytes:
+        mine = partials_fn(self.begin, self.count) if self.count else b""
+        if len(mine) != self.count * WINDOW_PARTIAL_BYTES:
+            raise ValueError("partials_fn returned %d bytes for %d windows" % (len(mine), self.count))
+        if self.world == 1:
+            return combine_partials_bytes(mine)
+        import torch.distributed as dist
+
+        if self.count:
+            self.send_host.numpy()[: len(mine)] = memoryview(mine)
+        self.send_dev.copy_(self.send_host, non_blocking=True)
+        dist.all_gather_into_tensor(self.recv_dev, self.send_dev, group=self.group)
+        self.recv_host.copy_(self.recv_dev)  # synchronising D2H (53 KB at most)
+        flat = self.recv_host.numpy()
+        parts = [flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts)]
+        return combine_partials_bytes(b"".join(parts))
+
+
 def sharded_msm(
     partials_fn: Callable[[int, int], bytes],
     rank: int,
