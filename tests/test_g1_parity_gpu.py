@@ -215,6 +215,39 @@ def test_sharded_msm_single_rank(engine, oracle):
     assert out == util.oracle_msm(oracle, pts, ks)
 
 
+def test_bucket_reduction_partials_against_oracle_window_sums(engine, oracle):
+    """a10 (BPR): every window's partial record -- plain bucket sum + 15 bit-plane sums -- weighs up to
+    the oracle's window sum (its BPR stage 1 + stage 2 + sum of the 256 partials, submission.ts:297-308)."""
+    n = 3000
+    pts, ks = seeded_inputs(oracle, n, 1010)
+    d_p, d_s = dev(pts), dev(ks)
+    rec = engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, 0, 16)
+    _, ws = util.oracle_msm_params(oracle, pts, ks, 16, 256, want_windows=True)
+    words = np.frombuffer(rec, dtype=np.uint32).reshape(16, 16, 52)
+    for w in (0, 1, 8, 15):
+        g = util.affine_from_xyzz_words(words[w, 0])
+        for l in range(15):
+            g = R.add(g, R.mul(util.affine_from_xyzz_words(words[w, 1 + l]), 1 << l))
+        assert R.encode_result(g) == ws[96 * w : 96 * w + 96], w
+
+
+def test_heavily_skewed_scalars_at_scale(engine, oracle):
+    """f2: 2^18 points whose scalars take only 3 values -- rows of ~87k entries are split into work items
+    and merged (the reference assumes uniform scalars, README.md:543-547).  Closed form: sum k_i P_i with
+    P_i = [a0 + i d]G."""
+    n = 1 << 18
+    a0, d = 0x9999999999, 0x77777
+    pts = util.oracle_gen_points(oracle, n, a0, d)
+    vals = R.rand_scalars(4, 3)
+    ks_int = [vals[i % 3] for i in range(n)]
+    total = sum(k * (a0 + i * d) for i, k in enumerate(ks_int)) % R.R_ORDER
+    exp = ctypes.create_string_buffer(96)
+    gen = ctypes.create_string_buffer(96)
+    oracle.oracle_g1_generator(ctypes.addressof(gen))
+    assert oracle.oracle_g1_scalar_mul(gen.raw, total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
+    assert engine.msm(pts, R.encode_scalars(ks_int)) == exp.raw
+
+
 def test_generate_bases(engine):
     """Synthetic inputs P_i = [a_i]G, a_i = SplitMix64(seed)."""
     import torch
@@ -254,3 +287,29 @@ def test_full_size_2_20_closed_form(engine, oracle):
     exp2 = ctypes.create_string_buffer(96)
     assert oracle.oracle_g1_scalar_mul(gen.raw, ((2 * total) % R.R_ORDER).to_bytes(32, "little"), 32, ctypes.addressof(exp2)) == 0
     assert engine.msm_fixed_base(ks2) == exp2.raw
+
+
+def test_2_22_closed_form(oracle):
+    """BASELINE.json configs[3] size on one GPU (the 8-GPU run shards the same problem by windows)."""
+    import webgpu_msm_bls12_377_amd as msm
+    import bench
+
+    n = 1 << 22
+    a0, d = 0xABCDEF0123456789ABCDEF, 0x1357924680ACE
+    pts = util.oracle_gen_points(oracle, n, a0, d)
+    ks = bench.seeded_scalars(0x5CA1A5 + 22, n)
+    ks_int = R.decode_scalars(ks)
+    total = sum(k * (a0 + i * d) for i, k in enumerate(ks_int)) % R.R_ORDER
+    exp = ctypes.create_string_buffer(96)
+    gen = ctypes.create_string_buffer(96)
+    oracle.oracle_g1_generator(ctypes.addressof(gen))
+    assert oracle.oracle_g1_scalar_mul(gen.raw, total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
+    with msm.MsmEngine(n) as eng:
+        d_p, d_s = dev(pts), dev(ks)
+        eng.set_timing(True)
+        got = eng.msm_device(d_p.data_ptr(), d_s.data_ptr(), n)
+        print("2^22 stage ms:", eng.stage_ms())
+        assert got == exp.raw
+        # the same problem as 8 window shards
+        parts = [eng.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, *msm.windows_for_rank(r, 8)) for r in range(8)]
+        assert msm.combine_partials(b"".join(parts)) == exp.raw

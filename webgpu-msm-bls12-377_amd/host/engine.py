@@ -8,6 +8,7 @@ MsmError(MSM377_EHIP) at context creation.
 """
 import ctypes
 import os
+import sys
 from typing import List, Optional, Sequence, Tuple
 
 NUM_WINDOWS = 16
@@ -51,6 +52,15 @@ def load_library():
             "msm377: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C webgpu-msm-bls12-377_amd/csrc`; there is no CPU fallback" % path
         )
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 with the same
+    # SONAME as /opt/rocm's.  If this library pulled in the system copy first, a later `import torch`
+    # would bind to it and fail ("No HIP GPUs are available"); loading torch's first makes both share
+    # one runtime (measured working on the MI355X box).  Hosts without torch (node, C) use /opt/rocm's.
+    if "torch" not in sys.modules and os.environ.get("MSM377_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional plumbing
+            pass
     lib = ctypes.CDLL(path)
     u8p, vp, u64, u32, i32 = ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     sigs = {
