@@ -6,7 +6,7 @@
 // /root/reference/src/submission/):
 //   k_convert_bases   wire x||y -> Montgomery records            wgsl/cuzk/convert_point_coords_and_decompose_scalars.template.wgsl:41-99 + barrett.template.wgsl:60-82
 //   k_decompose       scalars -> signed 16-bit digits            same file :100-141; model cuzk/utils.ts:66-109
-//   k_hist / k_chunk_prefix / k_scan_totals / k_scatter
+//   k_range_count / k_range_scan / k_partition / k_local_sort
 //                     per-window counting sort -> CSR            wgsl/cuzk/transpose_serial.wgsl:34-76 (16 serial threads there); model cuzk/transpose.ts:14-62
 //   k_accumulate      bucket sums (the dominant kernel)          wgsl/cuzk/smvp_bls12_377.template.wgsl:72-160
 //   k_tree_step       bucket reduction, log-depth bit planes     wgsl/cuzk/bpr.template.wgsl:69-173; models cuzk/bpr.ts:5-126
@@ -42,7 +42,7 @@ constexpr uint32_t NBIN = NB + 1;  // sort keys 0..32768 (key 0 = digit 0, never
 constexpr uint32_t RP = NBIN + 1;  // row_ptr entries per window
 constexpr uint32_t REC_WORDS = 32; // one base record, 128 bytes
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
-constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) pairs: one 131 KB LDS histogram per CU
+constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) blocks of the partition pass
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
 constexpr uint32_t SEG = 64;               // entries per accumulation work item (one thread); longer rows are split
 constexpr uint32_t SEG_BINS = SEG + 1;     // work items are counting-sorted by length 0..SEG
@@ -227,6 +227,17 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restric
   for (int k = 0; k < 8; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
 }
 
+// Sort keys: |d| in 0..32768 with the sign carried separately; coarse range = key / 128
+// (256 ranges; the last one also owns key 32768).
+constexpr uint32_t NRANGE = 256;
+constexpr uint32_t KRANGE = NB / NRANGE;  // 128 keys per range
+__device__ __forceinline__ void digit_key(uint32_t biased, uint32_t& key, uint32_t& sign) {
+  int d = (int)biased - 32768;
+  sign = d < 0 ? 1u : 0u;
+  key = (uint32_t)(d < 0 ? -d : d);
+}
+__device__ __forceinline__ uint32_t key_range(uint32_t key) { return key >= NB ? NRANGE - 1 : key / KRANGE; }
+
 // One thread per scalar: 16 signed digits d_w in [-2^15, 2^15), stored biased (d + 2^15).
 // Only windows [wb, wb + wc) are written (window sharding); the carry chain always runs over
 // all 16.  A final carry (scalar >= 2^255 - 2^239) sets *err, as cuzk/utils.ts:95-98 throws.
@@ -247,115 +258,186 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ 
   if (carry) atomicOr(err, 1);
 }
 
-__device__ __forceinline__ void digit_key(uint32_t biased, uint32_t& key, uint32_t& sign) {
-  int d = (int)biased - 32768;
-  sign = d < 0 ? 1u : 0u;
-  key = (uint32_t)(d < 0 ? -d : d);
+// ---- per-window counting sort (the reference's transpose, transpose_serial.wgsl:34-76) ----
+//
+// Two-level (MSD) counting sort; every pass touches each (window, point) element once:
+//   k_range_count  block (chunk, window): LDS histogram of the chunk over 256 coarse key ranges
+//   k_range_scan   block per window: region bases per range, per-chunk write offsets
+//   k_partition    block (chunk, window): appends each element (index|sign, key) to its
+//                  range's region at LDS-ranked offsets -- contiguous runs, no global atomics
+//   k_local_sort   block (range, window): counting sort of the region's <= 129 keys in LDS;
+//                  writes its row_ptr slice and its val_idx slice, a CONTIGUOUS output owned by
+//                  one block, so the 4-byte stores combine in that XCD's L2.
+// (The first version scattered straight from the digit columns: every 4-byte store then left
+// L2 as a partial write, 8x the payload, 213 us at n = 2^20.)  Order inside a bucket is free:
+// group addition commutes (the reference's transpose is stable only because it is serial).
+
+struct SortElem {
+  uint32_t idx_sign;  // point index | sign << 31
+  uint32_t key;       // |d|
+};
+
+// Calls f(i, biased_digit) for every i in [beg, end) of a digit column, eight digits per
+// 16-byte load where the address allows it (keeps 8x more bytes in flight per thread).
+template <class F>
+__device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ dg, uint64_t beg, uint64_t end, uint32_t tid, uint32_t nthreads, F f) {
+  uint64_t head = beg;
+  while (head < end && (((uintptr_t)(dg + head)) & 15)) head++;
+  for (uint64_t i = beg + tid; i < head; i += nthreads) f(i, (uint32_t)dg[i]);
+  const uint64_t groups = (end - head) / 8;
+  const uint4* v = reinterpret_cast<const uint4*>(dg + head);
+  for (uint64_t g = tid; g < groups; g += nthreads) {
+    const uint4 q = v[g];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      f(head + g * 8 + 2 * k, w[k] & 0xffffu);
+      f(head + g * 8 + 2 * k + 1, w[k] >> 16);
+    }
+  }
+  for (uint64_t i = head + groups * 8 + tid; i < end; i += nthreads) f(i, (uint32_t)dg[i]);
 }
 
-// ---- per-window counting sort (the reference's transpose, transpose_serial.wgsl:34-76) ----
-// One 131 KB LDS histogram per CU: block (chunk c, window slot ws) counts its chunk's keys
-// (k_hist), k_chunk_prefix turns the per-chunk counts into exclusive prefixes, k_scan_totals
-// scans the 32769 key totals into row_ptr, and k_scatter re-reads the chunk and hands every
-// element its slot with one LDS atomic.  (A key-range-partitioned variant with contiguous
-// output slices was measured slower: every block then filters the whole digit column.)
-
-// Block (chunk c, window slot ws): histogram of the chunk's keys in LDS (131 KB), written
-// out as hist_chunk[ws][c][key].
-__global__ void __launch_bounds__(1024) k_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ hist_chunk, uint64_t n,
-                                               uint32_t chunks, uint64_t per_chunk) {
-  extern __shared__ uint32_t lds[];
+__global__ void __launch_bounds__(1024) k_range_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts /* [ws][r][c] */,
+                                                      uint64_t n, uint32_t chunks, uint64_t per_chunk) {
+  __shared__ uint32_t cnt[NRANGE];
   const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
-  for (uint32_t k = tid; k < NBIN; k += 1024) lds[k] = 0;
+  if (tid < NRANGE) cnt[tid] = 0;
   __syncthreads();
   const uint64_t beg = (uint64_t)c * per_chunk;
   const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
-  const uint16_t* dg = digits + (size_t)ws * n;
-  for (uint64_t i = beg + tid; i < end; i += 1024) {
+  for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t, uint32_t biased) {
     uint32_t key, sign;
-    digit_key(dg[i], key, sign);
-    atomicAdd(&lds[key], 1u);
-  }
+    digit_key(biased, key, sign);
+    atomicAdd(&cnt[key_range(key)], 1u);
+  });
   __syncthreads();
-  uint32_t* out = hist_chunk + ((size_t)ws * chunks + c) * NBIN;
-  for (uint32_t k = tid; k < NBIN; k += 1024) out[k] = lds[k];
+  if (tid < NRANGE) counts[((size_t)ws * NRANGE + tid) * chunks + c] = cnt[tid];
 }
 
-// Thread per (key, window slot): exclusive prefix over the chunks, total into tot[].
-__global__ void __launch_bounds__(256) k_chunk_prefix(uint32_t* __restrict__ hist_chunk, uint32_t* __restrict__ tot, uint32_t chunks) {
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x, ws = blockIdx.y;
-  if (k >= NBIN) return;
-  uint32_t run = 0;
-  uint32_t* h = hist_chunk + (size_t)ws * chunks * NBIN + k;
+// Block per window slot, thread per range: region_base[r] = elements in smaller ranges;
+// counts[ws][r][c] becomes the write offset of chunk c inside region r (absolute).
+__global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_base, uint32_t chunks) {
+  __shared__ uint32_t part[NRANGE];
+  const uint32_t ws = blockIdx.x, r = threadIdx.x;
+  uint32_t* cr = counts + ((size_t)ws * NRANGE + r) * chunks;
+  uint32_t tot = 0;
+  for (uint32_t c = 0; c < chunks; c++) tot += cr[c];
+  part[r] = tot;
+  __syncthreads();
+  for (uint32_t off = 1; off < NRANGE; off <<= 1) {
+    const uint32_t v = r >= off ? part[r - off] : 0u;
+    __syncthreads();
+    part[r] += v;
+    __syncthreads();
+  }
+  const uint32_t base = part[r] - tot;
+  region_base[ws * (NRANGE + 1) + r] = base;
+  if (r == NRANGE - 1) region_base[ws * (NRANGE + 1) + NRANGE] = part[r];
+  uint32_t run = base;
   for (uint32_t c = 0; c < chunks; c++) {
-    uint32_t v = h[(size_t)c * NBIN];
-    h[(size_t)c * NBIN] = run;
+    const uint32_t v = cr[c];
+    cr[c] = run;
     run += v;
   }
-  tot[(size_t)ws * NBIN + k] = run;
 }
 
-// Block per window slot: row_ptr = exclusive scan of the 32769 key counts.  The counts are
-// staged in LDS so that global access is unit-stride while each thread scans 33 consecutive
-// entries (LDS stride 33 words: conflict-free).
-__global__ void __launch_bounds__(1024) k_scan_totals(const uint32_t* __restrict__ tot, uint32_t* __restrict__ row_ptr) {
-  extern __shared__ uint32_t lds[];  // NBIN counts, then 1024 partials
-  uint32_t* part = lds + NBIN;
-  const uint32_t ws = blockIdx.x, tid = threadIdx.x;
-  const uint32_t* t = tot + (size_t)ws * NBIN;
-  uint32_t* rp = row_ptr + (size_t)ws * RP;
-  constexpr uint32_t PER = (NBIN + 1023) / 1024;  // 33
-  for (uint32_t k = tid; k < NBIN; k += 1024) lds[k] = t[k];
+__global__ void __launch_bounds__(1024) k_partition(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
+                                                    SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk) {
+  __shared__ uint32_t cur[NRANGE];
+  const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  if (tid < NRANGE) cur[tid] = counts[((size_t)ws * NRANGE + tid) * chunks + c];
   __syncthreads();
-  const uint32_t base = tid * PER;
-  uint32_t s = 0;
-  for (uint32_t j = 0; j < PER; j++) {
-    const uint32_t k = base + j;
-    if (k < NBIN) s += lds[k];
+  const uint64_t beg = (uint64_t)c * per_chunk;
+  const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
+  SortElem* out = temp + (size_t)ws * n;
+  for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t i, uint32_t biased) {
+    uint32_t key, sign;
+    digit_key(biased, key, sign);
+    out[atomicAdd(&cur[key_range(key)], 1u)] = SortElem{(uint32_t)i | (sign << 31), key};
+  });
+}
+
+// Block (range r, window slot ws), 256 threads: the region holds exactly the elements with keys
+// in [r KRANGE, (r + 1) KRANGE) (plus key 32768 for the last range).  The region was written by
+// other CUs, so every load misses L2: a region of up to LS_CACHE elements (n / 256 = 4096 on
+// average at n = 2^20) is read ONCE, eight 8-byte loads in flight per thread, and kept in LDS for
+// the scatter pass; longer regions are streamed twice.
+constexpr uint32_t LS_CACHE = 6144;
+__global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
+                                                    uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n) {
+  __shared__ uint32_t bins[KRANGE + 1];
+  __shared__ uint32_t part[256];
+  __shared__ SortElem cache[LS_CACHE];
+  const uint32_t r = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t lo = r * KRANGE;
+  const bool last = r == NRANGE - 1;
+  const uint32_t rbeg = region_base[ws * (NRANGE + 1) + r], rend = region_base[ws * (NRANGE + 1) + r + 1];
+  const uint32_t len = rend - rbeg;
+  const bool cached = len <= LS_CACHE;
+  const SortElem* in = temp + (size_t)ws * n + rbeg;
+  if (tid <= KRANGE) bins[tid] = 0;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
+    SortElem e[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t i = i0 + u * 256 + tid;
+      e[u].key = 0xffffffffu;
+      if (i < len) e[u] = in[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t i = i0 + u * 256 + tid;
+      if (i < len) {
+        atomicAdd(&bins[e[u].key - lo], 1u);
+        if (cached) cache[i] = e[u];
+      }
+    }
   }
-  part[tid] = s;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t v = tid >= off ? part[tid - off] : 0;
+  const uint32_t own = tid < KRANGE ? bins[tid] : 0u;
+  part[tid] = own;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256; off <<= 1) {
+    const uint32_t v = tid >= off ? part[tid - off] : 0u;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = part[tid] - s;
-  for (uint32_t j = 0; j < PER; j++) {
-    const uint32_t k = base + j;
-    if (k < NBIN) {
-      const uint32_t c = lds[k];
-      lds[k] = run;
-      run += c;
-    }
+  uint32_t* rp = row_ptr + (size_t)ws * RP + lo;
+  const uint32_t start = rbeg + part[tid] - own;
+  __syncthreads();
+  if (tid < KRANGE) {
+    bins[tid] = start;
+    rp[tid] = start;
+  }
+  if (tid == KRANGE - 1 && last) {  // key 32768 and the end sentinel
+    bins[KRANGE] = start + own;
+    rp[KRANGE] = start + own;
+    rp[KRANGE + 1] = rend;
   }
   __syncthreads();
-  for (uint32_t k = tid; k < NBIN; k += 1024) rp[k] = lds[k];
-  if (tid == 1023) rp[NBIN] = part[1023];
-}
-
-// Block (chunk, window slot): cursor[key] = row_ptr[key] + (keys of earlier chunks) in LDS,
-// then every element takes its slot with one LDS atomic.  Order inside a bucket is free
-// (group addition commutes; the reference's transpose is stable only because it is serial).
-__global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ hist_chunk,
-                                                  const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
-                                                  uint32_t chunks, uint64_t per_chunk) {
-  extern __shared__ uint32_t lds[];
-  const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
-  const uint32_t* h = hist_chunk + ((size_t)ws * chunks + c) * NBIN;
-  const uint32_t* rp = row_ptr + (size_t)ws * RP;
-  for (uint32_t k = tid; k < NBIN; k += 1024) lds[k] = rp[k] + h[k];
-  __syncthreads();
-  const uint64_t beg = (uint64_t)c * per_chunk;
-  const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
-  const uint16_t* dg = digits + (size_t)ws * n;
   uint32_t* vi = val_idx + (size_t)ws * n;
-  for (uint64_t i = beg + tid; i < end; i += 1024) {
-    uint32_t key, sign;
-    digit_key(dg[i], key, sign);
-    uint32_t pos = atomicAdd(&lds[key], 1u);
-    vi[pos] = (uint32_t)i | (sign << 31);
+  if (cached) {
+    for (uint32_t i = tid; i < len; i += 256) {
+      const SortElem e = cache[i];
+      vi[atomicAdd(&bins[e.key - lo], 1u)] = e.idx_sign;
+    }
+  } else {
+    for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
+      SortElem e[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * 256 + tid;
+        if (i < len) e[u] = in[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * 256 + tid;
+        if (i < len) vi[atomicAdd(&bins[e[u].key - lo], 1u)] = e[u].idx_sign;
+      }
+    }
   }
 }
 
@@ -447,9 +529,9 @@ __global__ void __launch_bounds__(256) k_work_scatter(const uint32_t* __restrict
   }
 }
 
-// One thread per work item.
-template <class CV>
-__global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
+// One thread per work item.  OCC = waves per SIMD the register allocator must allow.
+template <class CV, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
                                                        const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf) {
@@ -667,8 +749,9 @@ struct msm377_ctx {
   uint32_t* d_raw_scalars = nullptr;  // cap x 8 words
   uint32_t* d_bases = nullptr;        // cap x 32 words
   uint16_t* d_digits = nullptr;       // 16 x cap
-  uint32_t* d_hist_chunk = nullptr;   // MAX_SORT_BLOCKS x NBIN
-  uint32_t* d_tot = nullptr;          // 16 x NBIN
+  uint32_t* d_range_counts = nullptr; // 16 x NRANGE x chunks: per-chunk range counts, then write offsets
+  uint32_t* d_region_base = nullptr;  // 16 x (NRANGE + 1)
+  SortElem* d_sort_temp = nullptr;    // 16 x cap partitioned (index|sign, key) pairs
   uint32_t* d_row_ptr = nullptr;      // 16 x RP
   uint32_t* d_val_idx = nullptr;      // 16 x cap
   uint32_t* d_buckets = nullptr;      // 16 x 52 x NB
@@ -690,6 +773,7 @@ struct msm377_ctx {
   bool last_is_g1 = false;
   bool capture = false;
   bool timing = false;
+  int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
   bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
   hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
   double stage_ms[MSM377_NUM_STAGES] = {};
@@ -749,15 +833,13 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
     const uint64_t want = (n + 4095) / 4096;  // at least ~4096 elements per block
     if (chunks > want) chunks = (uint32_t)(want ? want : 1);
     const uint64_t per_chunk = (n + chunks - 1) / chunks;
-    const size_t lds_bytes = NBIN * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_hist, dim3(chunks, wc), dim3(1024), lds_bytes, st, ctx->d_digits, ctx->d_hist_chunk, n, chunks, per_chunk);
+    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, ctx->d_digits, ctx->d_range_counts, n, chunks, per_chunk);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_chunk_prefix, dim3((NBIN + 255) / 256, wc), dim3(256), 0, st, ctx->d_hist_chunk, ctx->d_tot, chunks);
+    hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, ctx->d_range_counts, ctx->d_region_base, chunks);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_totals, dim3(wc), dim3(1024), (NBIN + 1024) * sizeof(uint32_t), st, ctx->d_tot, ctx->d_row_ptr);
+    hipLaunchKernelGGL(k_partition, dim3(chunks, wc), dim3(1024), 0, st, ctx->d_digits, ctx->d_range_counts, ctx->d_sort_temp, n, chunks, per_chunk);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scatter, dim3(chunks, wc), dim3(1024), lds_bytes, st, ctx->d_digits, ctx->d_hist_chunk, ctx->d_row_ptr,
-                       ctx->d_val_idx, n, chunks, per_chunk);
+    hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, ctx->d_sort_temp, ctx->d_region_base, ctx->d_row_ptr, ctx->d_val_idx, n);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -779,8 +861,12 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
     {
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
-      hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                         ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+      if (ctx->acc_occ == 3)
+        hipLaunchKernelGGL((k_accumulate<CV, 3>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+      else
+        hipLaunchKernelGGL((k_accumulate<CV, 2>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
     }
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters, ctx->d_split_rows,
@@ -881,6 +967,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   ctx->device = device;
   ctx->cap = max_points;
   if (const char* e = getenv("MSM377_REDUCE_FUSED")) ctx->reduce_fused = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   const uint64_t cap = max_points;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
@@ -888,8 +975,9 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
   dalloc((void**)&ctx->d_bases, cap * REC_WORDS * 4);
   dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
-  dalloc((void**)&ctx->d_hist_chunk, (size_t)MAX_SORT_BLOCKS * NBIN * 4);
-  dalloc((void**)&ctx->d_tot, (size_t)MSM377_NUM_WINDOWS * NBIN * 4);
+  dalloc((void**)&ctx->d_range_counts, (size_t)NRANGE * MAX_SORT_BLOCKS * 4);  // chunks * wc <= MAX_SORT_BLOCKS
+  dalloc((void**)&ctx->d_region_base, (size_t)MSM377_NUM_WINDOWS * (NRANGE + 1) * 4);
+  dalloc((void**)&ctx->d_sort_temp, cap * MSM377_NUM_WINDOWS * sizeof(SortElem));
   dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
@@ -904,11 +992,6 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   ok = ok && hipHostMalloc((void**)&ctx->h_err, sizeof(int)) == hipSuccess;
   for (int s = 0; ok && s < MSM377_NUM_STAGES; s++)
     for (int k = 0; k < 2; k++) ok = ok && hipEventCreate(&ctx->ev[s][k]) == hipSuccess;
-  const size_t lds_bytes = NBIN * sizeof(uint32_t);
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_totals), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)((NBIN + 1024) * sizeof(uint32_t))) == hipSuccess;
   if (!ok) {
     msm377_ctx_destroy(ctx);
     return MSM377_ENOMEM;
@@ -921,7 +1004,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_hist_chunk, ctx->d_tot,
+  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
                   ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
