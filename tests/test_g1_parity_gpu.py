@@ -140,9 +140,10 @@ def test_one_repeated_base_point(engine, oracle):
     assert engine.msm(pts, ks) == exp
 
 
-def test_all_same_scalar(engine, oracle):
-    """Maximally skewed buckets: every point lands in the same bucket of each window."""
-    n = 2048
+@pytest.mark.parametrize("n", [65, 130, 200, 2048])
+def test_all_same_scalar(engine, oracle, n):
+    """Maximally skewed buckets: every point lands in the same bucket of each window, so every row is
+    split into work items and merged (2, 3, 4 and 32 segments)."""
     pts, _ = seeded_inputs(oracle, n, 77)
     k = R.rand_scalars(78, 1)[0]
     ks = R.encode_scalars([k] * n)

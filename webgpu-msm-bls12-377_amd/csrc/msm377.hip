@@ -664,19 +664,23 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
 // duration is one serial addition (14 field multiplications, ~14 us).  Here four adjacent
 // lanes share one addition: every lane holds both operands, each lane performs ONE of the
 // independent multiplications of a round (operands chosen by lane role, so all lanes run the
-// same instruction stream) and the products are exchanged inside the quad with DPP
-// quad_perm moves (VALU, no LDS).  Four rounds instead of fourteen multiplications:
+// same instruction stream) and the products are exchanged inside the quad with wave
+// shuffles.  Four rounds instead of fourteen multiplications:
 //   1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1        P = U2 - U1, R = S2 - S1
 //   2: PP = P P    | RR = R R    | ZZ1 ZZ2      | ZZZ1 ZZZ2
 //   3: PPP = P PP  | Q = U1 PP   | ZZ3 = (ZZ1 ZZ2) PP | -               X3 = RR - PPP - 2Q
 //   4: R (Q - X3)  | S1 PPP      | -            | ZZZ3 = (ZZZ1 ZZZ2) PPP   Y3 = lane0 - lane1
 // Identity operands and P = 0 (equal / opposite points) fall back to the generic addition on
 // lane 0 of the quad.
+// Broadcast lane K of every quad to its four lanes.  ds_bpermute (__shfl), not DPP quad_perm:
+// the DPP form produced wrong sums inside the looped merge kernel on ROCm 7.2 (the shuffle form
+// is bit-exact everywhere), and the crossbar cost is invisible next to a field multiplication.
 template <int K>
 __device__ __forceinline__ Fp::El quad_bcast(const Fp::El& v) {
   Fp::El r;
+  const int src = (int)(((threadIdx.x & 63u) & ~3u) | (uint32_t)K);
 #pragma unroll
-  for (int j = 0; j < 13; j++) r.l[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[j], K * 0x55, 0xf, 0xf, false);
+  for (int j = 0; j < 13; j++) r.l[j] = (uint32_t)__shfl((int)v.l[j], src, 64);
   return r;
 }
 __device__ __forceinline__ Fp::El sel4(uint32_t q, const Fp::El& a0, const Fp::El& a1, const Fp::El& a2, const Fp::El& a3) {
@@ -690,46 +694,67 @@ __device__ __forceinline__ Fp::El sel4(uint32_t q, const Fp::El& a0, const Fp::E
   return r;
 }
 
+// a + b computed by the four lanes of a quad (q = lane & 3); every lane passes the same a, b
+// and every lane receives the full sum.
+__device__ __forceinline__ G1XYZZ g1_add_quad(const G1XYZZ& a, const G1XYZZ& b, uint32_t q) {
+  const Fp::El m1 = Fp::mul(sel4(q, a.x, b.x, a.y, b.y), sel4(q, b.zz, a.zz, b.zzz, a.zzz));
+  const Fp::El u1 = quad_bcast<0>(m1), u2 = quad_bcast<1>(m1), s1 = quad_bcast<2>(m1), s2 = quad_bcast<3>(m1);
+  const Fp::El p = Fp::sub(u2, u1), rr0 = Fp::sub(s2, s1);
+  if (G1::is_identity(a) || G1::is_identity(b) || Fp::is_zero(p)) return G1::add(a, b);  // uniform inside the quad
+  const Fp::El m2 = Fp::mul(sel4(q, p, rr0, a.zz, a.zzz), sel4(q, p, rr0, b.zz, b.zzz));
+  const Fp::El pp = quad_bcast<0>(m2), rsq = quad_bcast<1>(m2);
+  const Fp::El m3 = Fp::mul(sel4(q, p, u1, m2, p), pp);  // lane 3 idles on a copy of lane 0's product
+  const Fp::El ppp = quad_bcast<0>(m3), qq = quad_bcast<1>(m3);
+  G1XYZZ o;
+  o.x = Fp::sub(Fp::sub(rsq, ppp), Fp::dbl(qq));
+  const Fp::El m4 = Fp::mul(sel4(q, rr0, s1, rr0, m2), sel4(q, Fp::sub(qq, o.x), ppp, ppp, ppp));
+  o.y = Fp::sub(quad_bcast<0>(m4), quad_bcast<1>(m4));
+  o.zz = quad_bcast<2>(m3);
+  o.zzz = quad_bcast<3>(m4);
+  return o;
+}
+
 // One reduction level r (same index scheme as k_tree_step) with a quad per addition.
 __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window) {
   const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   const uint32_t g = gid >> 2, q = threadIdx.x & 3;
   const uint32_t ws = blockIdx.y;
-  if (g >= ops_per_window) return;  // ops_per_window * 4 is a multiple of 4: whole quads leave together
+  if (g >= ops_per_window) return;  // whole quads leave together
   const uint32_t half = NB >> (r + 1);
   const uint32_t oi = g / half, kk = g % half;
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
   const uint32_t x = lo + kk, y = x + half;
-  const G1XYZZ a = load_bucket<G1Dev>(buckets, ws, x);
-  const G1XYZZ b = load_bucket<G1Dev>(buckets, ws, y);
-  const Fp::El m1 = Fp::mul(sel4(q, a.x, b.x, a.y, b.y), sel4(q, b.zz, a.zz, b.zzz, a.zzz));
-  const Fp::El u1 = quad_bcast<0>(m1), u2 = quad_bcast<1>(m1), s1 = quad_bcast<2>(m1), s2 = quad_bcast<3>(m1);
-  const Fp::El p = Fp::sub(u2, u1), rr0 = Fp::sub(s2, s1);
-  if (G1::is_identity(a) || G1::is_identity(b) || Fp::is_zero(p)) {  // uniform inside the quad
-    if (q == 0) store_bucket<G1Dev>(buckets, ws, x, G1::add(a, b));
-    return;
-  }
-  const Fp::El m2 = Fp::mul(sel4(q, p, rr0, a.zz, a.zzz), sel4(q, p, rr0, b.zz, b.zzz));
-  const Fp::El pp = quad_bcast<0>(m2), rsq = quad_bcast<1>(m2);
-  const Fp::El m3 = Fp::mul(sel4(q, p, u1, m2, p), pp);  // lane 3 idles on a copy of lane 0's product
-  const Fp::El ppp = quad_bcast<0>(m3), qq = quad_bcast<1>(m3);
-  const Fp::El x3 = Fp::sub(Fp::sub(rsq, ppp), Fp::dbl(qq));
-  const Fp::El m4 = Fp::mul(sel4(q, rr0, s1, rr0, m2), sel4(q, Fp::sub(qq, x3), ppp, ppp, ppp));
-  const Fp::El t2 = quad_bcast<1>(m4);
-  uint32_t* base = buckets + (size_t)ws * G1Dev::PT_WORDS * NB + x;
-  if (q == 0) {
-    const Fp::El y3 = Fp::sub(m4, t2);
+  const G1XYZZ sum = g1_add_quad(load_bucket<G1Dev>(buckets, ws, x), load_bucket<G1Dev>(buckets, ws, y), q);
+  // each lane stores one coordinate
+  const Fp::El c = sel4(q, sum.x, sum.y, sum.zz, sum.zzz);
+  uint32_t* base = buckets + ((size_t)ws * G1Dev::PT_WORDS + 13 * q) * NB + x;
 #pragma unroll
-    for (int j = 0; j < 13; j++) {
-      base[(size_t)j * NB] = x3.l[j];
-      base[(size_t)(13 + j) * NB] = y3.l[j];
+  for (int j = 0; j < 13; j++) base[(size_t)j * NB] = c.l[j];
+}
+
+// Quad per split row: bucket += its overflow partials (G1).
+__global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
+                                                                  const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
+                                                                  const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf) {
+  const uint32_t count = counters[0];
+  const uint32_t q = threadIdx.x & 3;
+  for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {
+    const uint32_t row = split_rows[i];
+    const uint32_t len = row_len(row_ptr, row);
+    const uint32_t nseg = (len + SEG - 1) / SEG;
+    const uint32_t ws = row / NB, t = row % NB;
+    G1XYZZ acc = load_bucket<G1Dev>(buckets, ws, t);
+    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * G1Dev::PT_WORDS;
+    G1XYZZ nxt = load_point_aos<G1Dev>(src);
+    for (uint32_t s = 1; s < nseg; s++) {
+      const G1XYZZ cur = nxt;
+      if (s + 1 < nseg) nxt = load_point_aos<G1Dev>(src + (size_t)s * G1Dev::PT_WORDS);
+      acc = g1_add_quad(acc, cur, q);
     }
-  } else if (q == 2) {
+    const Fp::El c = sel4(q, acc.x, acc.y, acc.zz, acc.zzz);
+    uint32_t* base = buckets + ((size_t)ws * G1Dev::PT_WORDS + 13 * q) * NB + t;
 #pragma unroll
-    for (int j = 0; j < 13; j++) base[(size_t)(26 + j) * NB] = m3.l[j];
-  } else if (q == 3) {
-#pragma unroll
-    for (int j = 0; j < 13; j++) base[(size_t)(39 + j) * NB] = m4.l[j];
+    for (int j = 0; j < 13; j++) base[(size_t)j * NB] = c.l[j];
   }
 }
 
@@ -848,6 +873,7 @@ struct msm377_ctx {
   bool capture = false;
   bool timing = false;
   uint32_t coop_from = 7;  // first reduction level run with one addition per lane quad (MSM377_COOP_FROM; 15 = never): measured 18-24 -> 13-18 us per level from level 7 on, slower before
+  bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
   int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
   bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
   hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
@@ -944,8 +970,12 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
                            ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
     }
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters, ctx->d_split_rows,
-                       ctx->d_row_ovf_base, ctx->d_ovf);
+    if (CV::PT_WORDS == G1Dev::PT_WORDS && ctx->merge_quad)
+      hipLaunchKernelGGL(k_merge_split_rows_quad, dim3(4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
+                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf);
+    else
+      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
+                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->capture) {
@@ -1046,6 +1076,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   ctx->cap = max_points;
   if (const char* e = getenv("MSM377_REDUCE_FUSED")) ctx->reduce_fused = atoi(e) != 0;
   if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
+  if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   const uint64_t cap = max_points;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
