@@ -65,6 +65,65 @@ def seeded_scalars(seed, n):
     return bytes(out)
 
 
+def side_workload(args, torch, msm, n):
+    """Informational lines for BASELINE.json configs[2] (Edwards) and configs[4] (64 fixed-base MSMs)."""
+    eng = msm.MsmEngine(n, device=0)
+    scalars_host = seeded_scalars(0x5CA1A5, n)
+    out = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "unit": "ms", "higher_is_better": False, "data": "synthetic",
+           "scaling": "strong", "vs_baseline": None}
+    if args.workload == "ed":
+        sub = 2111115437357092606062206234695386632838870926408408195193685246394721360383  # AleoConstants.ts:5
+        ks = b"".join((int.from_bytes(scalars_host[32 * i : 32 * i + 32], "little") % sub).to_bytes(32, "little") for i in range(n))
+        d_points = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+        eng.ed_generate_bases_device(0xED, n, d_points.data_ptr())
+        d_scalars = torch.frombuffer(bytearray(ks), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        step = lambda: eng.ed_msm_device(d_points.data_ptr(), d_scalars.data_ptr(), n)  # noqa: E731
+        per_step = 1
+        out.update({"metric": "ms per 2^%d Twisted-Edwards BLS12 MSM" % args.log_n, "dtype": "u32 (9 x 29-bit limbs)",
+                    "config": {"workload": "2^%d Edwards-BLS12 MSM (extended coordinates, add-2008-hwcd-3), 64-byte points, inputs resident" % args.log_n}})
+        alg = 32 * n + 64 * n + NUM_WINDOWS * 64 * n + 2 * NUM_WINDOWS * NUM_BUCKETS * 128 + 64
+    else:
+        batch = 64
+        d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
+        eng.generate_bases_device(0x377, n, d_points.data_ptr())
+        eng.set_bases_device(d_points.data_ptr(), n)
+        # 64 scalar sets: the seeded set rotated by b entries (distinct MSMs, no 2 GB of host bignum work)
+        d_one = torch.frombuffer(bytearray(scalars_host), dtype=torch.uint8).cuda().view(n, 32)
+        d_scalars = torch.cat([torch.roll(d_one, shifts=b, dims=0) for b in range(batch)]).contiguous().view(-1)
+        torch.cuda.synchronize()
+        step = lambda: eng.msm_fixed_base_batch_device(d_scalars.data_ptr(), n, batch)  # noqa: E731
+        per_step = batch
+        out.update({"metric": "ms per 2^%d fixed-base BLS12-377 G1 MSM (batch of 64, resident bases)" % args.log_n,
+                    "dtype": "u32 (29-bit limbs, 64-bit accumulate)",
+                    "config": {"workload": "64 x 2^%d fixed-base G1 MSMs over one HBM-resident converted base set, host tail overlapped" % args.log_n}})
+        alg = 32 * n + NUM_WINDOWS * 96 * n + 2 * NUM_WINDOWS * NUM_BUCKETS * 144 + 96
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / max(1, args.steps) / per_step
+    out.update({"value": round(ms, 4), "ms_per_step": round(ms * per_step, 4), "whole_job_hbm_GBps": round(alg / (ms * 1e-3) / 1e9, 2)})
+    if args.workload == "ed" and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import util
+
+        oracle = util.load_oracle()
+        ph = d_points.cpu().numpy().tobytes()
+        t1 = time.perf_counter()
+        cpu = util.oracle_ed_msm(oracle, ph, ks)
+        cpu_ms = (time.perf_counter() - t1) * 1e3
+        if cpu != res:
+            raise SystemExit("PARITY FAILURE: HIP Edwards result differs from the CPU oracle")
+        out["cpu_baseline"] = {"value": round(cpu_ms, 1), "unit": "ms per 2^%d MSM" % args.log_n, "cores": int(oracle.oracle_omp_threads()),
+                               "kind": "port", "sample": "the full workload, 1 run, same inputs; bit-exact with the GPU's"}
+    print(json.dumps(out), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +131,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 of the point count (default 20: the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument(
+        "--workload",
+        choices=["g1", "ed", "fixed64"],
+        default="g1",
+        help="g1 = the metric's workload (BASELINE.json configs[1], default); ed = configs[2] Twisted-Edwards MSM; "
+        "fixed64 = configs[4] 64 fixed-base MSMs over one HBM-resident base set (informational lines, single GPU)",
+    )
     args = ap.parse_args()
 
     import torch
@@ -104,6 +170,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = 1 << args.log_n
+    if args.workload != "g1":
+        if world != 1:
+            raise SystemExit("--workload %s is a single-GPU informational run" % args.workload)
+        return side_workload(args, torch, msm, n)
     eng = msm.MsmEngine(n, device=local_rank)
     d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
     eng.generate_bases_device(0x377, n, d_points.data_ptr())

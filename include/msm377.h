@@ -77,6 +77,9 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
 /* ... then run any number of MSMs of n scalars (host or device pointer) against it. */
 int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]);
 int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint8_t out_xy[96]);
+/* `batch` MSMs over the resident bases in one call: d_scalars holds batch x n x 32 bytes, out_xy
+ * receives batch x 96 bytes.  The host tail of MSM b overlaps the GPU work of MSM b+1. */
+int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy);
 
 /* Window sharding for multi-GPU runs (the reference already treats the
  * 16 window subtasks as independent, submission.ts:199-224).  Computes windows

@@ -191,6 +191,27 @@ def test_fixed_base_batches(engine, oracle):
     assert e.value.code == -5
 
 
+def test_fixed_base_batch_pipeline(engine, oracle):
+    """BASELINE.json config 5 shape: one resident base set, a batch of scalar sets in ONE call (the host
+    tail of each MSM overlaps the next MSM's GPU work); every result equals the oracle's."""
+    n, batch = 2500, 5
+    pts, _ = seeded_inputs(oracle, n, 55)
+    sets = [R.encode_scalars(R.rand_scalars(7000 + b, n)) for b in range(batch)]
+    engine.set_bases(pts)
+    d_s = dev(b"".join(sets))
+    got = engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, batch)
+    assert got == [util.oracle_msm(oracle, pts, s) for s in sets]
+    assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 1) == got[:1]
+    # an out-of-range scalar anywhere in the batch is reported, and the context stays usable
+    bad = bytearray(b"".join(sets))
+    bad[32 * (n + 3) : 32 * (n + 4)] = b"\xff" * 32
+    d_bad = dev(bytes(bad))
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm_fixed_base_batch_device(d_bad.data_ptr(), n, batch)
+    assert e.value.code == -3
+    assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 2) == got[:2]
+
+
 @pytest.mark.parametrize("world", [1, 2, 4, 8, 3])
 def test_window_sharding_on_one_gpu(engine, oracle, world):
     """BASELINE.json config 4's data path with every rank's window block run on this one GPU: the

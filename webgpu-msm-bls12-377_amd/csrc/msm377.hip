@@ -855,16 +855,17 @@ struct msm377_ctx {
   uint32_t* d_val_idx = nullptr;      // 16 x cap
   uint32_t* d_buckets = nullptr;      // 16 x 52 x NB
   uint32_t* d_buckets_snap = nullptr; // stage capture only
-  uint32_t* d_partials = nullptr;     // 16 x 16 x 52
+  uint32_t* d_partials = nullptr;     // 2 slots x 16 x 16 x 52 (double-buffered for batches)
   WorkItem* d_work = nullptr;         // sorted accumulation work items (<= 16 NB + 16 cap / SEG)
   uint32_t* d_work_meta = nullptr;    // [0..SEG] length histogram, [SEG_BINS..] cursors, then total, split-row count, overflow count
   uint32_t* d_row_ovf_base = nullptr; // 16 x NB
   uint32_t* d_split_rows = nullptr;   // 16 x NB
   uint32_t* d_ovf = nullptr;          // overflow partial points, 52 words each (<= 16 cap / SEG)
-  int* d_err = nullptr;
+  int* d_err = nullptr;               // 2 slots
   // pinned host
-  uint32_t* h_partials = nullptr;
-  int* h_err = nullptr;
+  uint32_t* h_partials = nullptr;     // 2 slots
+  int* h_err = nullptr;               // 2 slots
+  hipEvent_t done_ev[2] = {};
   // state
   uint64_t bases_n = 0;  // resident base count (fixed-base mode)
   uint64_t last_n = 0;
@@ -917,15 +918,20 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
   return MSM377_OK;
 }
 
-// Stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases; leaves the
-// partial records in ctx->h_partials (wc x 16 x PT_WORDS words) and synchronises the stream.
+constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * PT_WORDS;  // per double-buffer slot
+
+// Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
+// the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
+// Nothing here waits for the GPU.
 template <class CV>
-int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc) {
+int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc, int slot) {
   hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), st));
+  int* d_err = ctx->d_err + slot;
+  uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
+  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE);
-    hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, ctx->d_err);
+    hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, d_err);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -997,15 +1003,22 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
         hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_gather_partials, dim3(wc, MSM377_G1_PARTIAL_POINTS), dim3(64), 0, st, ctx->d_buckets, ctx->d_partials, CV::PT_WORDS);
+    hipLaunchKernelGGL(k_gather_partials, dim3(wc, MSM377_G1_PARTIAL_POINTS), dim3(64), 0, st, ctx->d_buckets, d_partials, CV::PT_WORDS);
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::PT_WORDS * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::PT_WORDS * 4,
+                               hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err + slot, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipEventRecord(ctx->done_ev[slot], st));
   ctx->last_n = n;
   ctx->last_wc = wc;
   ctx->last_is_g1 = CV::PT_WORDS == G1Dev::PT_WORDS;
+  return MSM377_OK;
+}
+
+// Wait for slot `slot`; its partial records are then in ctx->h_partials + slot * SLOT_WORDS.
+int finish_windows(msm377_ctx* ctx, int slot) {
+  HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
   if (ctx->timing) {
     for (int s = 0; s < MSM377_NUM_STAGES; s++) {
       if (s == MSM377_STAGE_TAIL) continue;  // host wall time, set by the caller
@@ -1013,11 +1026,18 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
       if (hipEventElapsedTime(&ms, ctx->ev[s][0], ctx->ev[s][1]) == hipSuccess) ctx->stage_ms[s] = ms;
     }
   }
-  if (*ctx->h_err) {
+  if (ctx->h_err[slot]) {
     ctx->err = "a scalar overflows the signed 16-bit window recode (final carry)";
     return MSM377_ESCALAR;
   }
   return MSM377_OK;
+}
+
+template <class CV>
+int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc) {
+  int rc = enqueue_windows<CV>(ctx, d_scalars, n, wb, wc, 0);
+  if (rc) return rc;
+  return finish_windows(ctx, 0);
 }
 
 int check_args(msm377_ctx* ctx, const void* a, const void* b, uint64_t n, bool need_a) {
@@ -1091,15 +1111,16 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
-  dalloc((void**)&ctx->d_partials, (size_t)MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
+  dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
   dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG + 1) * sizeof(WorkItem));
   dalloc((void**)&ctx->d_work_meta, (size_t)(2 * SEG_BINS + 4) * 4);
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG + 1) * PT_WORDS * 4);
-  dalloc((void**)&ctx->d_err, sizeof(int));
-  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&ctx->h_err, sizeof(int)) == hipSuccess;
+  dalloc((void**)&ctx->d_err, 2 * sizeof(int));
+  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
+  for (int k = 0; ok && k < 2; k++) ok = ok && hipEventCreateWithFlags(&ctx->done_ev[k], hipEventDisableTiming) == hipSuccess;
   for (int s = 0; ok && s < MSM377_NUM_STAGES; s++)
     for (int k = 0; k < 2; k++) ok = ok && hipEventCreate(&ctx->ev[s][k]) == hipSuccess;
   if (!ok) {
@@ -1120,6 +1141,8 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  for (int k = 0; k < 2; k++)
+    if (ctx->done_ev[k]) (void)hipEventDestroy(ctx->done_ev[k]);
   for (int s = 0; s < MSM377_NUM_STAGES; s++)
     for (int k = 0; k < 2; k++)
       if (ctx->ev[s][k]) (void)hipEventDestroy(ctx->ev[s][k]);
@@ -1247,6 +1270,40 @@ int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint
   rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
   if (rc) return rc;
   return finish_full(ctx, out_xy);
+}
+
+int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy) {
+  if (!out_xy) return MSM377_EINVAL;
+  int rc = check_args(ctx, nullptr, d_scalars, n, false);
+  if (rc) return rc;
+  if (n > ctx->bases_n) {
+    ctx->err = "fixed-base MSM needs msm377_g1_set_bases with at least n points first";
+    return MSM377_ESTATE;
+  }
+  if (n == 0) {
+    for (uint32_t b = 0; b < batch; b++) identity_wire(out_xy + (size_t)96 * b);
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t* sc = (const uint32_t*)d_scalars;
+  // Software pipeline over the batch: while the GPU runs MSM b, the host finishes MSM b-1
+  // (Horner + inversion on the other slot's partial records).
+  for (uint32_t b = 0; b <= batch; b++) {
+    if (b < batch) {
+      rc = enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, MSM377_NUM_WINDOWS, (int)(b & 1));
+      if (rc) return rc;
+    }
+    if (b > 0) {
+      const int slot = (int)((b - 1) & 1);
+      rc = finish_windows(ctx, slot);
+      if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+      }
+      g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, out_xy + (size_t)96 * (b - 1));
+    }
+  }
+  return MSM377_OK;
 }
 
 int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {

@@ -75,6 +75,7 @@ def load_library():
         "msm377_g1_set_bases_device": (i32, [vp, vp, u64]),
         "msm377_g1_msm_fixed_base": (i32, [vp, u8p, u64, vp]),
         "msm377_g1_msm_fixed_base_device": (i32, [vp, vp, u64, vp]),
+        "msm377_g1_msm_fixed_base_batch_device": (i32, [vp, vp, u64, u32, vp]),
         "msm377_g1_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_combine_partials": (i32, [vp, vp]),
         "msm377_g1_generate_bases_device": (i32, [vp, u64, u64, vp]),
@@ -197,6 +198,16 @@ class MsmEngine:
         out = ctypes.create_string_buffer(96)
         self._check(self._lib.msm377_g1_msm_fixed_base_device(self._ctx, d_scalars, int(n), ctypes.addressof(out)), "msm377_g1_msm_fixed_base_device")
         return out.raw
+
+    def msm_fixed_base_batch_device(self, d_scalars: int, n: int, batch: int) -> List[bytes]:
+        """`batch` MSMs of n scalars each (contiguous in HBM) against the resident bases; the host tail
+        of one MSM overlaps the GPU work of the next."""
+        out = ctypes.create_string_buffer(96 * max(1, batch))
+        self._check(
+            self._lib.msm377_g1_msm_fixed_base_batch_device(self._ctx, d_scalars, int(n), int(batch), ctypes.addressof(out)),
+            "msm377_g1_msm_fixed_base_batch_device",
+        )
+        return [out.raw[96 * b : 96 * b + 96] for b in range(batch)]
 
     def window_partials_device(self, d_points: int, d_scalars: int, n: int, win_begin: int, win_count: int) -> bytes:
         """Partial records of windows [win_begin, win_begin + win_count) (multi-GPU sharding)."""
