@@ -28,6 +28,7 @@
 
 #include <chrono>
 #include <string>
+#include <thread>
 
 #include "../../include/msm377.h"
 #include "fp64_host.hpp"
@@ -866,6 +867,9 @@ struct msm377_ctx {
   uint32_t* h_partials = nullptr;     // 2 slots
   int* h_err = nullptr;               // 2 slots
   hipEvent_t done_ev[2] = {};
+  // host-buffer entry points: pinned staging + copy workers (allocated on first use)
+  uint8_t* h_stage = nullptr;  // cap x 128 bytes
+  hipStream_t copy_stream[4] = {};
   // state
   uint64_t bases_n = 0;  // resident base count (fixed-base mode)
   uint64_t last_n = 0;
@@ -892,6 +896,49 @@ bool hip_ok(msm377_ctx* ctx, hipError_t e, const char* what) {
   do {                                                \
     if (!hip_ok((ctx), (call), #call)) return MSM377_EHIP; \
   } while (0)
+
+// Pageable host memory -> device through a pinned staging buffer: four workers copy 8 MB chunks
+// into it and queue the DMA of each chunk on their own stream, so the CPU copy of one chunk
+// overlaps the DMA of the others.  Measured on the MI355X box for 160 MB: 4.2 ms, against 28 ms
+// for a first hipMemcpy from fresh pageable pages (4.4 ms once the runtime has pinned them) and
+// 3.3 + 2.9 ms for hipHostRegister + copy.  Returns when the data is on the device.
+int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, size_t stage_off) {
+  constexpr int NT = 4;
+  constexpr size_t CHUNK = 8u << 20;
+  if (bytes < CHUNK) {  // not worth four threads
+    HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return MSM377_OK;
+  }
+  if (!ctx->h_stage) {
+    if (hipHostMalloc((void**)&ctx->h_stage, (size_t)ctx->cap * 128) != hipSuccess) {
+      ctx->h_stage = nullptr;
+      HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));  // fall back to the runtime's pageable path
+      return MSM377_OK;
+    }
+    for (int t = 0; t < NT; t++) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
+  }
+  const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+  uint8_t* stage = ctx->h_stage + stage_off;
+  hipError_t errs[NT];
+  std::thread workers[NT];
+  const int device = ctx->device;
+  for (int t = 0; t < NT; t++) {
+    errs[t] = hipSuccess;
+    workers[t] = std::thread([=, &errs] {
+      hipError_t e = hipSetDevice(device);
+      for (size_t c = t; c < nchunks && e == hipSuccess; c += NT) {
+        const size_t off = c * CHUNK, len = (bytes - off < CHUNK) ? bytes - off : CHUNK;
+        memcpy(stage + off, src + off, len);
+        e = hipMemcpyAsync((uint8_t*)d_dst + off, stage + off, len, hipMemcpyHostToDevice, ctx->copy_stream[t]);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream[t]);
+      errs[t] = e;
+    });
+  }
+  for (int t = 0; t < NT; t++) workers[t].join();
+  for (int t = 0; t < NT; t++) HIP_TRY(ctx, errs[t]);
+  return MSM377_OK;
+}
 
 void identity_wire(uint8_t out[96]) {
   memset(out, 0, 96);
@@ -1141,6 +1188,9 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (int t = 0; t < 4; t++)
+    if (ctx->copy_stream[t]) (void)hipStreamDestroy(ctx->copy_stream[t]);
   for (int k = 0; k < 2; k++)
     if (ctx->done_ev[k]) (void)hipEventDestroy(ctx->done_ev[k]);
   for (int s = 0; s < MSM377_NUM_STAGES; s++)
@@ -1181,8 +1231,9 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
     return MSM377_OK;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_scalars, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 96, 0);
+  if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
+  if (rc) return rc;
   return msm377_g1_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
 }
 
@@ -1217,8 +1268,9 @@ int msm377_ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
   }
   if (n == 0) return msm377_ed_msm_device(ctx, nullptr, nullptr, 0, out_xy);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, points, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_scalars, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 64, 0);
+  if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
+  if (rc) return rc;
   return msm377_ed_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
 }
 
@@ -1246,7 +1298,8 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
 int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n) {
   if (!ctx || n > ctx->cap || (n && !points)) return MSM377_EINVAL;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 96, 0);
+  if (rc) return rc;
   return msm377_g1_set_bases_device(ctx, ctx->d_raw_points, n);
 }
 
@@ -1309,7 +1362,8 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
 int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
   if (!ctx || !out_xy || n > ctx->cap || (n && !scalars)) return MSM377_EINVAL;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_scalars, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  int rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
+  if (rc) return rc;
   return msm377_g1_msm_fixed_base_device(ctx, ctx->d_raw_scalars, n, out_xy);
 }
 
