@@ -41,9 +41,9 @@ extern "C" {
 #define MSM377_NUM_WINDOWS 16          /* ceil(256 / 16): submission.ts:108-109 */
 #define MSM377_WINDOW_BITS 16          /* chunk_size for n >= 2^16: submission.ts:97 */
 /* One window's partial result: 16 points (plain bucket sum + 15 bit-plane sums), each four
- * 13-word Montgomery coordinates (X, Y, ZZ, ZZZ). */
+ * coordinates (X, Y, ZZ, ZZZ) of 12 little-endian u32 words in Montgomery form, radix 2^384. */
 #define MSM377_G1_PARTIAL_POINTS 16
-#define MSM377_G1_POINT_WORDS 52
+#define MSM377_G1_POINT_WORDS 48
 #define MSM377_G1_WINDOW_PARTIAL_BYTES (MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS * 4)
 
 typedef struct msm377_ctx msm377_ctx;

@@ -245,11 +245,11 @@ def test_bucket_reduction_partials_against_oracle_window_sums(engine, oracle):
     d_p, d_s = dev(pts), dev(ks)
     rec = engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, 0, 16)
     _, ws = util.oracle_msm_params(oracle, pts, ks, 16, 256, want_windows=True)
-    words = np.frombuffer(rec, dtype=np.uint32).reshape(16, 16, 52)
+    words = np.frombuffer(rec, dtype=np.uint32).reshape(16, 16, 48)
     for w in (0, 1, 8, 15):
-        g = util.affine_from_xyzz_words(words[w, 0])
+        g = util.affine_from_record_words(words[w, 0])
         for l in range(15):
-            g = R.add(g, R.mul(util.affine_from_xyzz_words(words[w, 1 + l]), 1 << l))
+            g = R.add(g, R.mul(util.affine_from_record_words(words[w, 1 + l]), 1 << l))
         assert R.encode_result(g) == ws[96 * w : 96 * w + 96], w
 
 

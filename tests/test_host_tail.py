@@ -12,10 +12,10 @@ import webgpu_msm_bls12_377_amd as msm
 from webgpu_msm_bls12_377_amd.host import engine as E
 
 
-def record(points16):
+def record(points16, rnd=None):
     words = []
     for pt in points16:
-        words += util.xyzz_words_from_affine(pt)
+        words += util.record_point_words(pt, rnd.randrange(1, R.P) if rnd else 1)
     return struct.pack("<%dI" % len(words), *words)
 
 
@@ -37,7 +37,7 @@ def test_combine_matches_definition():
     recs, expect = [], None
     for w in range(16):
         pts16 = [rnd.choice(base + [None]) for _ in range(16)]
-        recs.append(record(pts16))
+        recs.append(record(pts16, rnd))
         g = pts16[0]
         for l in range(15):
             g = R.add(g, R.mul(pts16[1 + l], 1 << l))

@@ -137,10 +137,36 @@ def affine_from_xyzz_words(words):
     return (X * pow(ZZ, -1, R.P) % R.P, Y * pow(ZZZ, -1, R.P) % R.P)
 
 
+R64 = 1 << 384  # Montgomery radix of the partial records (host-tail format)
+
+
+def _words12(v):
+    return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
+
+
+def record_point_words(pt, z=1):
+    """One point of a window partial record (include/msm377.h): X, Y, ZZ, ZZZ as 12 u32 words each,
+    Montgomery form with radix 2^384; None (the identity) has ZZ = ZZZ = 0."""
+    if pt is None:
+        return _words12(0) + _words12(R64 % R.P) + [0] * 24
+    zz, zzz = z * z % R.P, z * z * z % R.P
+    return (_words12(pt[0] * zz * R64 % R.P) + _words12(pt[1] * zzz * R64 % R.P) + _words12(zz * R64 % R.P) + _words12(zzz * R64 % R.P))
+
+
+def affine_from_record_words(words):
+    """Inverse of record_point_words via Python ints."""
+    ri = pow(R64, -1, R.P)
+    X, Y, ZZ, ZZZ = (sum(int(w) << (32 * i) for i, w in enumerate(words[12 * c : 12 * c + 12])) * ri % R.P for c in range(4))
+    if ZZ == 0:
+        return None
+    assert pow(ZZ, 3, R.P) == pow(ZZZ, 2, R.P), "XYZZ invariant ZZ^3 = ZZZ^2 violated"
+    return (X * pow(ZZ, -1, R.P) % R.P, Y * pow(ZZZ, -1, R.P) % R.P)
+
+
 def partial_record_from_window_sum(pt) -> bytes:
     """A window partial record (include/msm377.h) whose point 0 is the window sum and whose 15
     bit-plane points are the identity."""
     import struct
 
-    words = xyzz_words_from_affine(pt) + (to_limbs29_mont(0) + to_limbs29_mont(1) + [0] * 26) * 15
+    words = record_point_words(pt) + record_point_words(None) * 15
     return struct.pack("<%dI" % len(words), *words)

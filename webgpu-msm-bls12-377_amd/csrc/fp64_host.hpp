@@ -121,7 +121,6 @@ struct FieldHost64 {
     memcpy(r.v, t, sizeof r.v);
     return r;
   }
-  static El sqr(const El& a) { return mul(a, a); }
   static El inv(const El& a) {  // a^(p-2); p is odd and p = 1 mod 4 here, so only the low word changes
     El r = one();
     for (int i = 64 * NW - 1; i >= 0; i--) {
@@ -129,6 +128,57 @@ struct FieldHost64 {
       uint64_t w = C::MOD[i >> 6] - ((i >> 6) == 0 ? 2 : 0);
       if ((w >> (i & 63)) & 1) r = mul(r, a);
     }
+    return r;
+  }
+  static El from_words32(const uint32_t* w) {  // 2 NW little-endian u32 words, already in this Montgomery form
+    El x;
+    for (int i = 0; i < NW; i++) x.v[i] = ((uint64_t)w[2 * i + 1] << 32) | w[2 * i];
+    return x;
+  }
+  // Montgomery square: 21 + 36 word products instead of 72 for NW = 6.
+  static El sqr(const El& a) {
+    uint64_t t[2 * NW + 1];
+    for (int i = 0; i <= 2 * NW; i++) t[i] = 0;
+    for (int i = 0; i < NW; i++) {  // off-diagonal products, once
+      uint64_t carry = 0;
+      for (int j = i + 1; j < NW; j++) {
+        u128 acc = (u128)a.v[i] * a.v[j] + t[i + j] + carry;
+        t[i + j] = (uint64_t)acc;
+        carry = (uint64_t)(acc >> 64);
+      }
+      t[i + NW] = carry;
+    }
+    uint64_t top = 0;  // double
+    for (int i = 0; i < 2 * NW; i++) {
+      const uint64_t v = t[i];
+      t[i] = (v << 1) | top;
+      top = v >> 63;
+    }
+    uint64_t carry = 0;  // add the squares
+    for (int i = 0; i < NW; i++) {
+      u128 acc = (u128)a.v[i] * a.v[i] + t[2 * i] + carry;
+      t[2 * i] = (uint64_t)acc;
+      acc = (u128)t[2 * i + 1] + (uint64_t)(acc >> 64);
+      t[2 * i + 1] = (uint64_t)acc;
+      carry = (uint64_t)(acc >> 64);
+    }
+    for (int i = 0; i < NW; i++) {  // Montgomery reduction, one word per round
+      const uint64_t m = t[i] * C::N0;
+      uint64_t c = 0;
+      for (int j = 0; j < NW; j++) {
+        u128 acc = (u128)m * C::MOD[j] + t[i + j] + c;
+        t[i + j] = (uint64_t)acc;
+        c = (uint64_t)(acc >> 64);
+      }
+      for (int k = i + NW; c && k <= 2 * NW; k++) {
+        u128 acc = (u128)t[k] + c;
+        t[k] = (uint64_t)acc;
+        c = (uint64_t)(acc >> 64);
+      }
+    }
+    if (t[2 * NW] || geq_p(t + NW)) sub_p(t + NW);
+    El r;
+    memcpy(r.v, t + NW, sizeof r.v);
     return r;
   }
   // F29::N x 29-bit limbs in the device's Montgomery form -> this format.
@@ -157,13 +207,23 @@ using Fq64 = FieldHost64<EdConsts64, Fq>;
 // ---- G1 tail ----
 using G1H = G1T<Fp64>;
 
-// X, Y, ZZ, ZZZ (13 device limbs each) -> host point.
+// X, Y, ZZ, ZZZ (13 device limbs each, device Montgomery form) -> host point.
 inline G1H::XYZZ g1h_from_device_words(const uint32_t* w52) {
   G1H::XYZZ p;
   p.x = Fp64::from_limbs29_mont(w52);
   p.y = Fp64::from_limbs29_mont(w52 + 13);
   p.zz = Fp64::from_limbs29_mont(w52 + 26);
   p.zzz = Fp64::from_limbs29_mont(w52 + 39);
+  return p;
+}
+// One point of a partial record: X, Y, ZZ, ZZZ as 12 u32 words each, already in the host's
+// Montgomery form (k_gather_partials re-bases on the GPU).
+inline G1H::XYZZ g1h_from_record_words(const uint32_t* w48) {
+  G1H::XYZZ p;
+  p.x = Fp64::from_words32(w48);
+  p.y = Fp64::from_words32(w48 + 12);
+  p.zz = Fp64::from_words32(w48 + 24);
+  p.zzz = Fp64::from_words32(w48 + 36);
   return p;
 }
 
@@ -185,16 +245,16 @@ inline void g1h_to_wire(const G1H::XYZZ& p, uint8_t out[96]) {
 // Horner over the 16 x 16 partial points of a full MSM.  Window w contributes
 //   G_w = Sum_w + sum_l 2^l * Plane_{w,l}      (Plane_{w,l} = sum of buckets whose (t-1) has bit l)
 // and the MSM is sum_w 2^(16 w) G_w (submission.ts:310-318), i.e. one 256-step double-and-add
-// over bit positions b = 16 w + l.  partials layout: [window][point][52 words], point 0 =
+// over bit positions b = 16 w + l.  partials layout: [window][point][48 words], point 0 =
 // Sum_w, point 1 + l = Plane_{w,l}.
 inline void g1h_combine(const uint32_t* partials, uint8_t out[96]) {
   G1H::XYZZ acc = G1H::identity();
   for (int b = 255; b >= 0; b--) {
     acc = G1H::dbl(acc);
     const int w = b >> 4, l = b & 15;
-    const uint32_t* base = partials + (size_t)w * 16 * 52;
-    if (l < 15) acc = G1H::add(acc, g1h_from_device_words(base + (size_t)(1 + l) * 52));
-    if (l == 0) acc = G1H::add(acc, g1h_from_device_words(base));
+    const uint32_t* base = partials + (size_t)w * 16 * 48;
+    if (l < 15) acc = G1H::add(acc, g1h_from_record_words(base + (size_t)(1 + l) * 48));
+    if (l == 0) acc = G1H::add(acc, g1h_from_record_words(base));
   }
   g1h_to_wire(acc, out);
 }
@@ -205,12 +265,12 @@ struct EdK64 {
 };
 using EdH = EdT<Fq64, EdK64>;
 
-inline EdH::Ext edh_from_device_words(const uint32_t* w36) {
+inline EdH::Ext edh_from_record_words(const uint32_t* w32) {  // X, Y, T, Z as 8 u32 words each, host Montgomery form
   EdH::Ext p;
-  p.x = Fq64::from_limbs29_mont(w36);
-  p.y = Fq64::from_limbs29_mont(w36 + 9);
-  p.t = Fq64::from_limbs29_mont(w36 + 18);
-  p.z = Fq64::from_limbs29_mont(w36 + 27);
+  p.x = Fq64::from_words32(w32);
+  p.y = Fq64::from_words32(w32 + 8);
+  p.t = Fq64::from_words32(w32 + 16);
+  p.z = Fq64::from_words32(w32 + 24);
   return p;
 }
 inline void edh_to_wire(const EdH::Ext& p, uint8_t out[64]) {
@@ -218,15 +278,15 @@ inline void edh_to_wire(const EdH::Ext& p, uint8_t out[64]) {
   Fq64::to_wire(Fq64::mul(p.x, zi), out);
   Fq64::to_wire(Fq64::mul(p.y, zi), out + 32);
 }
-// Same Horner as g1h_combine; partials layout [window][point][36 words].
+// Same Horner as g1h_combine; partials layout [window][point][32 words].
 inline void edh_combine(const uint32_t* partials, uint8_t out[64]) {
   EdH::Ext acc = EdH::identity();
   for (int b = 255; b >= 0; b--) {
     acc = EdH::dbl(acc);
     const int w = b >> 4, l = b & 15;
-    const uint32_t* base = partials + (size_t)w * 16 * 36;
-    if (l < 15) acc = EdH::add(acc, edh_from_device_words(base + (size_t)(1 + l) * 36));
-    if (l == 0) acc = EdH::add(acc, edh_from_device_words(base));
+    const uint32_t* base = partials + (size_t)w * 16 * 32;
+    if (l < 15) acc = EdH::add(acc, edh_from_record_words(base + (size_t)(1 + l) * 32));
+    if (l == 0) acc = EdH::add(acc, edh_from_record_words(base));
   }
   edh_to_wire(acc, out);
 }

@@ -68,6 +68,10 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ p, uin
 struct G1Dev {
   static constexpr uint32_t RAW_WORDS = 24;  // wire: x || y, 48 bytes each
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, ZZ, ZZZ
+  static constexpr uint32_t OUT_WORDS = 48;  // a partial-record point: 4 coordinates x 12 u32 (host-tail format)
+  using F = Fp;
+  static constexpr uint32_t NL = 13, NW32 = 12;
+  static __device__ __forceinline__ Fp::El to64() { return Fp::from_const(G1Consts::TO64); }
   using Base = G1Affine;
   using Pt = G1XYZZ;
   static __device__ __forceinline__ void convert(const uint32_t* raw, uint32_t* rec) {
@@ -125,6 +129,10 @@ struct G1Dev {
 struct EdDev {
   static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
   static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
+  static constexpr uint32_t OUT_WORDS = 32;  // a partial-record point: 4 coordinates x 8 u32 (host-tail format)
+  using F = Fq;
+  static constexpr uint32_t NL = 9, NW32 = 8;
+  static __device__ __forceinline__ Fq::El to64() { return Fq::from_const(EdConsts::TO64); }
   using Base = Ed::Base;
   using Pt = Ed::Ext;
   // record: (y - x)[9] (y + x)[9] (2d x y)[9] pad[5]
@@ -759,12 +767,25 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
   }
 }
 
-// Pack the 16 partial points of every window slot: point 0 = B[0], point 1 + l = B[2^l].
-__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t pt_words) {
-  const uint32_t ws = blockIdx.x, pt = blockIdx.y, j = threadIdx.x;
-  if (j >= pt_words) return;
+// Pack the 16 partial points of every window slot (point 0 = B[0], point 1 + l = B[2^l]) in the
+// HOST TAIL's format: each coordinate re-based from the device's Montgomery radix 2^(29 NL) to
+// 2^(32 NW32) and written as NW32 little-endian u32 words, so the host does no conversion
+// multiplications.  One thread per (window slot, point, coordinate).
+template <class CV>
+__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t wc) {
+  const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= wc * MSM377_G1_PARTIAL_POINTS * 4) return;
+  const uint32_t coord = g & 3, pt = (g >> 2) % MSM377_G1_PARTIAL_POINTS, ws = g / (4 * MSM377_G1_PARTIAL_POINTS);
   const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
-  out[((size_t)ws * MSM377_G1_PARTIAL_POINTS + pt) * pt_words + j] = buckets[((size_t)ws * pt_words + j) * NB + x];
+  typename CV::F::El v;
+#pragma unroll
+  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = buckets[((size_t)ws * CV::PT_WORDS + coord * CV::NL + j) * NB + x];
+  v = CV::F::mul(v, CV::to64());
+  uint32_t w[CV::NW32];
+  CV::F::template to_words<CV::NW32>(v, w);
+  uint32_t* o = out + ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
+#pragma unroll
+  for (uint32_t j = 0; j < CV::NW32; j++) o[j] = w[j];
 }
 
 // Synthetic bases: P_i = [a_i]G with a_i the (i+1)-th SplitMix64(seed) output, wire format.
@@ -965,7 +986,7 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
   return MSM377_OK;
 }
 
-constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * PT_WORDS;  // per double-buffer slot
+constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot
 
 // Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
 // the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
@@ -1050,10 +1071,10 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint
         hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_gather_partials, dim3(wc, MSM377_G1_PARTIAL_POINTS), dim3(64), 0, st, ctx->d_buckets, d_partials, CV::PT_WORDS);
+    hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, ctx->d_buckets, d_partials, wc);
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::PT_WORDS * 4,
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
                                hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err + slot, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipEventRecord(ctx->done_ev[slot], st));

@@ -14,8 +14,9 @@ from typing import List, Optional, Sequence, Tuple
 NUM_WINDOWS = 16
 WINDOW_BITS = 16
 PARTIAL_POINTS = 16
-POINT_WORDS = 52
-WINDOW_PARTIAL_BYTES = PARTIAL_POINTS * POINT_WORDS * 4
+POINT_WORDS = 52  # a bucket point in the device format (stage read-backs)
+RECORD_POINT_WORDS = 48  # a point of a window partial record (host-tail format)
+WINDOW_PARTIAL_BYTES = PARTIAL_POINTS * RECORD_POINT_WORDS * 4
 NUM_BUCKETS = 32768
 STAGE_NAMES = ("convert", "decompose", "sort", "accumulate", "reduce", "tail", "accumulate_kernel")
 
