@@ -46,6 +46,22 @@ def algorithmic_bytes(n):
     return whole, accumulate
 
 
+def pmc_traffic_bytes(log_n):
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    separate passes; FETCH_SIZE doubled per the gfx950 note in /opt/skills/guides/MI355X_MICROARCH.md).  Only valid
+    for the workload the passes were taken on (2^20); None otherwise or when no summary is committed."""
+    if log_n != 20:
+        return None
+    for tag in ("r01_final", "r01_c"):
+        path = os.path.join(ROOT, "profiles", tag, "pmc_summary.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                k = json.load(f).get("k_accumulate", {})
+            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                return int((2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    return None
+
+
 def seeded_scalars(seed, n):
     """n scalars uniform below r: four SplitMix64 outputs per scalar, reduced mod r (identical to
     tests/pyref.py:rand_scalars)."""
@@ -249,7 +265,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(args.log_n) if world == 1 else None,
+                "traffic_source": "profiles/*/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x2 per the gfx950 note)",
                 "algorithmic_bytes_per_launch": int(acc_bytes_launch),
                 "kernel_ms": round(acc_ms, 4),
             },
