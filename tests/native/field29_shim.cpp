@@ -40,6 +40,10 @@ void shim_fp_ops(const uint32_t* a, const uint32_t* b, uint32_t* mul, uint32_t* 
   store(Fp::sqr(x), sqr);
   store(Fp::neg(x), neg);
 }
+// a*b - c*d through the fused single-reduction path
+void shim_fp_mul_sub_mul(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+  store(Fp::mul_sub_mul(load(a), load(b), load(c), load(d)), out);
+}
 // raw Montgomery limbs of to_mont(a): checks the limb format itself
 void shim_fp_to_mont_limbs(const uint32_t* a, uint32_t* limbs13) {
   Fp::El x = load(a);

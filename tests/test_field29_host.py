@@ -47,6 +47,18 @@ def test_field_ops(shim):
         assert got == [a * b % R.P, (a + b) % R.P, (a - b) % R.P, a * a % R.P, (-a) % R.P], (a, b)
 
 
+def test_fused_mul_sub_mul(shim):
+    """a*b - c*d with one reduction (Y3 of every point addition): extremes maximise the unreduced value."""
+    rnd = random.Random(99)
+    special = [0, 1, R.P - 1, R.P - 2, (R.P - 1) // 2, 1 << 376]
+    vals = special + [rnd.randrange(R.P) for _ in range(60)]
+    for it in range(2000):
+        a, b, c, d = (rnd.choice(vals) for _ in range(4)) if it >= 300 else (rnd.choice(special) for _ in range(4))
+        out = (ctypes.c_uint32 * 12)()
+        shim.shim_fp_mul_sub_mul(words12(a), words12(b), words12(c), words12(d), out)
+        assert from_words(out) == (a * b - c * d) % R.P, (a, b, c, d)
+
+
 def test_montgomery_limb_format(shim):
     rnd = random.Random(1)
     for v in [0, 1, R.P - 1] + [rnd.randrange(R.P) for _ in range(50)]:

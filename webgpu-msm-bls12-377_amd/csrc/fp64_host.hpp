@@ -130,6 +130,7 @@ struct FieldHost64 {
     }
     return r;
   }
+  static El mul_sub_mul(const El& a, const El& b, const El& c, const El& d) { return sub(mul(a, b), mul(c, d)); }
   static El from_words32(const uint32_t* w) {  // 2 NW little-endian u32 words, already in this Montgomery form
     El x;
     for (int i = 0; i < NW; i++) x.v[i] = ((uint64_t)w[2 * i + 1] << 32) | w[2 * i];

@@ -64,7 +64,7 @@ struct G1T {
     El m = F::add(F::dbl(xx), xx);
     XYZZ r;
     r.x = F::sub(F::sqr(m), F::dbl(s));
-    r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+    r.y = F::mul_sub_mul(m, F::sub(s, r.x), w, p.y);
     r.zz = F::mul(v, p.zz);
     r.zzz = F::mul(w, p.zzz);
     return r;
@@ -80,7 +80,7 @@ struct G1T {
     El m = F::add(F::dbl(xx), xx);
     XYZZ r;
     r.x = F::sub(F::sqr(m), F::dbl(s));
-    r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+    r.y = F::mul_sub_mul(m, F::sub(s, r.x), w, p.y);
     r.zz = v;
     r.zzz = w;
     return r;
@@ -102,7 +102,7 @@ struct G1T {
     El qq = F::mul(a.x, pp);
     XYZZ o;
     o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
-    o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(a.y, ppp));
+    o.y = F::mul_sub_mul(r, F::sub(qq, o.x), a.y, ppp);
     o.zz = F::mul(a.zz, pp);
     o.zzz = F::mul(a.zzz, ppp);
     return o;
@@ -127,7 +127,7 @@ struct G1T {
     El qq = F::mul(u1, pp);
     XYZZ o;
     o.x = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
-    o.y = F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(s1, ppp));
+    o.y = F::mul_sub_mul(r, F::sub(qq, o.x), s1, ppp);
     o.zz = F::mul(F::mul(a.zz, b.zz), pp);
     o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
     return o;

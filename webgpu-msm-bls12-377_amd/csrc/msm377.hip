@@ -473,13 +473,13 @@ __device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr
   return rp[2] - rp[1];
 }
 
-// Thread per row: length histogram of its work items (LDS, then one global atomic per bin and
-// block); rows with more than one item reserve overflow slots and join the split-row list.
-__global__ void __launch_bounds__(256) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ work_hist,
+// Thread per row, 1024 rows per block: length histogram of its work items (LDS, then one global
+// atomic per bin and block -- the ~60 hot counters serialise, hence the large blocks); rows with more than one item reserve overflow slots and join the split-row list.
+__global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ work_hist,
                                                    uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
                                                    uint32_t* __restrict__ split_rows) {
   __shared__ uint32_t lh[SEG_BINS];
-  const uint32_t tid = threadIdx.x, row = blockIdx.x * 256 + tid;
+  const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
   if (tid < SEG_BINS) lh[tid] = 0;
   __syncthreads();
   if (row < rows) {
@@ -512,11 +512,11 @@ __global__ void __launch_bounds__(128) k_work_scan(const uint32_t* __restrict__ 
 }
 
 // Thread per row again: claims its slots in the sorted work list.
-__global__ void __launch_bounds__(256) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ cursor,
+__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ cursor,
                                                       WorkItem* __restrict__ work) {
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t lbase[SEG_BINS];
-  const uint32_t tid = threadIdx.x, row = blockIdx.x * 256 + tid;
+  const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
   if (tid < SEG_BINS) lh[tid] = 0;
   __syncthreads();
   uint32_t nfull = 0, rem = 0, rank_full = 0, rank_rem = 0;
@@ -1026,12 +1026,12 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
     HIP_TRY(ctx, hipMemsetAsync(meta, 0, (size_t)(2 * SEG_BINS + 4) * 4, st));
-    hipLaunchKernelGGL(k_work_hist, dim3(rows / 256), dim3(256), 0, st, ctx->d_row_ptr, rows, work_hist, ctx->d_row_ovf_base, counters,
+    hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, work_hist, ctx->d_row_ovf_base, counters,
                        ctx->d_split_rows);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(128), 0, st, work_hist, cursor, total);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 256), dim3(256), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
+    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
     {
