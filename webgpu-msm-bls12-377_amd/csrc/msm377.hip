@@ -863,6 +863,8 @@ __global__ void __launch_bounds__(256, 2) k_generate_bases_ed(uint64_t seed, uin
 struct msm377_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;      // base conversion, overlapped with decompose + sort
+  hipEvent_t bases_ready = nullptr;
   uint64_t cap = 0;
   std::string err;
   // device buffers
@@ -979,10 +981,16 @@ struct StageTimer {
 
 template <class CV>
 int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
-  StageTimer t(ctx, MSM377_STAGE_CONVERT);
+  // Runs on the side stream: it depends on the points only, while decomposition and the sort
+  // depend on the scalars only, so the two overlap (HBM-bound vs LDS/latency-bound);
+  // k_accumulate waits for `bases_ready`.  Every entry point ends with a host-side wait for the
+  // main stream, so the previous call's readers of d_bases are done.
   if (n == 0) return MSM377_OK;
-  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, ctx->d_bases, n);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream2);
+  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
   HIP_TRY(ctx, hipGetLastError());
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream2);
+  HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
   return MSM377_OK;
 }
 
@@ -1034,9 +1042,13 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint
     hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->bases_ready, 0));
     {
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
-      if (ctx->acc_occ == 3)
+      if (ctx->acc_occ == 4)
+        hipLaunchKernelGGL((k_accumulate<CV, 4>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+      else if (ctx->acc_occ == 3)
         hipLaunchKernelGGL((k_accumulate<CV, 3>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
                            ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
       else
@@ -1167,7 +1179,9 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   const uint64_t cap = max_points;
-  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess;
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
   dalloc((void**)&ctx->d_raw_points, cap * 96);
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
@@ -1203,6 +1217,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
                   ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
   for (void* p : bufs)
@@ -1217,6 +1232,8 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   for (int s = 0; s < MSM377_NUM_STAGES; s++)
     for (int k = 0; k < 2; k++)
       if (ctx->ev[s][k]) (void)hipEventDestroy(ctx->ev[s][k]);
+  if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1311,7 +1328,7 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   ctx->bases_n = n;
   return MSM377_OK;
 }
