@@ -124,6 +124,14 @@ int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint3
 /* Convert one Montgomery XYZZ point (52 words) to the affine wire format (host-only). */
 int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
 
+/* Optional GLV front end for the G1 full-MSM entry points (msm, msm_device, set_bases +
+ * fixed_base*): k = k1 + k2 LAMBDA, 8 windows over the 2n points {P_i, phi(P_i)} (SURVEY.md
+ * section 8 row f4).  Results are identical; scalars outside the GLV range (>~ 2^254) rerun on the
+ * plain 16-window path automatically.  Off by default (it halves the bucket reduction and the
+ * host tail but slows the accumulation kernel: 3.67 vs 3.63 ms at n = 2^20); stage read-backs
+ * need the plain path; window sharding always uses the plain 16 windows. */
+int msm377_ctx_set_glv(msm377_ctx* ctx, int enabled);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 #define MSM377_STAGE_CONVERT 0     /* points -> Montgomery records */

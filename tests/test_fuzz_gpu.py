@@ -65,7 +65,13 @@ def test_g1_fuzz(engine, oracle, seed):
     n = rnd.choice([1, 2, 3, 7, 63, 64, 65, 129, 500, 1500, 3000])
     pts, ks = fuzz_case(rnd, n, R.R_ORDER, g1_points(oracle))
     pb, sb = R.encode_points(pts), R.encode_scalars(ks)
-    assert engine.msm(pb, sb) == util.oracle_msm(oracle, pb, sb)
+    exp = util.oracle_msm(oracle, pb, sb)
+    assert engine.msm(pb, sb) == exp
+    engine.set_glv(True)  # the optional GLV front end on the same inputs
+    try:
+        assert engine.msm(pb, sb) == exp
+    finally:
+        engine.set_glv(False)
 
 
 @pytest.mark.parametrize("seed", range(12))

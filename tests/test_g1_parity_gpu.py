@@ -75,6 +75,7 @@ def test_stage_parity(engine, oracle):
     n = 5000
     pts, ks = seeded_inputs(oracle, n, 4242)
     engine.set_stage_capture(True)
+    engine.set_glv(False)  # the stage read-backs describe the plain 16-window path (the default)
     try:
         res = engine.msm(pts, ks)
         assert res == util.oracle_msm(oracle, pts, ks)
@@ -115,6 +116,42 @@ def test_stage_parity(engine, oracle):
             assert nonempty > 1000
     finally:
         engine.set_stage_capture(False)
+
+
+@pytest.mark.parametrize("glv", [True, False])
+def test_glv_and_plain_front_ends(engine, oracle, golden, glv):
+    """f4: the GLV front end (k = k1 + k2 LAMBDA, 8 windows over {P_i, phi(P_i)}) and the plain 16-window path
+    give the oracle's result on the same inputs."""
+    engine.set_glv(glv)
+    try:
+        for name, case in golden.items():
+            if name.startswith("g1_"):
+                assert engine.msm(case["points"], case["scalars"]) == case["expected"], name
+        for n in (1, 2, 77, 1000, 20000):
+            pts, ks = seeded_inputs(oracle, n, 31 + n)
+            assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks), n
+    finally:
+        engine.set_glv(False)
+
+
+def test_scalars_outside_the_glv_range_fall_back(engine, oracle):
+    """k >= ~2^254 does not split into two 127-bit halves: the call reruns on the plain path (which accepts
+    scalars up to 2^255 - 2^239) and still returns sum k_i P_i."""
+    n = 300
+    pts, ks = seeded_inputs(oracle, n, 909)
+    ks_int = R.decode_scalars(ks)
+    ks_int[17] = (1 << 254) + 123456789
+    ks_int[200] = (1 << 255) - (1 << 240)
+    ks2 = R.encode_scalars(ks_int)
+    exp = R.encode_result(R.msm_naive(R.decode_points(pts), ks_int))
+    engine.set_glv(True)
+    try:
+        assert engine.msm(pts, ks2) == exp
+        engine.set_bases(pts)
+        assert engine.msm_fixed_base(ks2) == exp
+        assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
+    finally:
+        engine.set_glv(False)
 
 
 def test_bucket_boundaries_and_signs(engine, oracle):
@@ -191,17 +228,29 @@ def test_fixed_base_batches(engine, oracle):
     assert e.value.code == -5
 
 
-def test_fixed_base_batch_pipeline(engine, oracle):
+@pytest.mark.parametrize("glv", [False, True])
+def test_fixed_base_batch_pipeline(engine, oracle, glv):
     """BASELINE.json config 5 shape: one resident base set, a batch of scalar sets in ONE call (the host
     tail of each MSM overlaps the next MSM's GPU work); every result equals the oracle's."""
     n, batch = 2500, 5
     pts, _ = seeded_inputs(oracle, n, 55)
     sets = [R.encode_scalars(R.rand_scalars(7000 + b, n)) for b in range(batch)]
+    engine.set_glv(glv)
     engine.set_bases(pts)
+    engine.set_glv(False)  # the resident table remembers how it was built
     d_s = dev(b"".join(sets))
     got = engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, batch)
     assert got == [util.oracle_msm(oracle, pts, s) for s in sets]
     assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 1) == got[:1]
+    # one element of the batch outside the GLV range: that element alone reruns on the plain path
+    ks_int = R.decode_scalars(sets[2])
+    ks_int[5] = (1 << 254) + 99
+    mixed = list(sets)
+    mixed[2] = R.encode_scalars(ks_int)
+    d_m = dev(b"".join(mixed))
+    got_m = engine.msm_fixed_base_batch_device(d_m.data_ptr(), n, batch)
+    assert got_m[:2] == got[:2] and got_m[3:] == got[3:]
+    assert got_m[2] == R.encode_result(R.msm_naive(R.decode_points(pts), ks_int))
     # an out-of-range scalar anywhere in the batch is reported, and the context stays usable
     bad = bytearray(b"".join(sets))
     bad[32 * (n + 3) : 32 * (n + 4)] = b"\xff" * 32

@@ -80,14 +80,56 @@ def emit64(ns, mod, n, n29, extra=None):
     return out
 
 
+# GLV endomorphism of BLS12-377 G1: phi(x, y) = (BETA x, y) = [LAMBDA](x, y), LAMBDA = x0^2 - 1 for the curve
+# parameter x0 (r = x0^4 - x0^2 + 1, so LAMBDA^2 + LAMBDA + 1 = 0 mod r).  k = k1 + k2 LAMBDA with
+# k2 = floor(k / LAMBDA), k1 = k mod LAMBDA: both non-negative and < 2^127 for k < r.
+X0 = 0x8508C00000000001
+GLV_LAMBDA = X0 * X0 - 1
+GLV_BETA = None  # found at generation time by _find_beta()
+
+
+def _find_beta():
+    """The primitive cube root of unity in Fp with (beta x, y) = [LAMBDA](x, y) on the generator."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import pyref as R
+
+    t = 2
+    while pow(t, (P - 1) // 3, P) == 1:
+        t += 1
+    b = pow(t, (P - 1) // 3, P)
+    target = R.mul(R.G, GLV_LAMBDA)
+    for beta in (b, b * b % P):
+        if (beta * GX % P, GY) == target:
+            return beta
+    raise AssertionError("no beta matches LAMBDA")
+
+
+def emit_glv():
+    assert (GLV_LAMBDA * GLV_LAMBDA + GLV_LAMBDA + 1) % Q == 0 and GLV_LAMBDA.bit_length() == 127
+    mu = (1 << 384) // GLV_LAMBDA
+
+    def words(v, n):
+        return ", ".join("0x%08xu" % ((v >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
+
+    out = "struct GlvConsts {  // k = k1 + k2 LAMBDA; Barrett quotient with MU = floor(2^384 / LAMBDA)\n"
+    out += "static constexpr uint32_t LAMBDA[4] = {%s};\n" % words(GLV_LAMBDA, 4)
+    out += "static constexpr uint32_t MU[9] = {%s};\n" % words(mu, 9)
+    out += "};\n\n"
+    return out
+
+
 def main():
+    global GLV_BETA
+    GLV_BETA = _find_beta()
     assert (GY * GY - GX ** 3 - 1) % P == 0
     assert (-ED_GX * ED_GX + ED_GY * ED_GY - 1 - ED_D * ED_GX * ED_GX * ED_GY * ED_GY) % Q == 0
     here = os.path.dirname(os.path.abspath(__file__))
     dst = os.path.join(here, "..", "webgpu-msm-bls12-377_amd", "csrc", "consts_gen.hpp")
     s = "// GENERATED by tools/gen_consts.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\n"
     s += "namespace msm377 {\n\n"
-    s += emit("G1Consts", P, 13, {"GEN_X": GX, "GEN_Y": GY, "B3": 3})
+    s += emit("G1Consts", P, 13, {"GEN_X": GX, "GEN_Y": GY, "B3": 3, "BETA": GLV_BETA})
+    s += emit_glv()
     s += emit("EdConsts", Q, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D, "GEN_X": ED_GX, "GEN_Y": ED_GY})
     s += emit64("G1Consts64", P, 6, 13)
     s += emit64("EdConsts64", Q, 4, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D})

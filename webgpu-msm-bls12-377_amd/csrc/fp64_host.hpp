@@ -245,12 +245,13 @@ inline void g1h_to_wire(const G1H::XYZZ& p, uint8_t out[96]) {
 
 // Horner over the 16 x 16 partial points of a full MSM.  Window w contributes
 //   G_w = Sum_w + sum_l 2^l * Plane_{w,l}      (Plane_{w,l} = sum of buckets whose (t-1) has bit l)
-// and the MSM is sum_w 2^(16 w) G_w (submission.ts:310-318), i.e. one 256-step double-and-add
-// over bit positions b = 16 w + l.  partials layout: [window][point][48 words], point 0 =
+// and the MSM is sum_w 2^(16 w) G_w (submission.ts:310-318), i.e. one (16 num_windows)-step
+// double-and-add over bit positions b = 16 w + l (16 windows on the plain path, 8 behind the GLV
+// front end).  partials layout: [window][point][48 words], point 0 =
 // Sum_w, point 1 + l = Plane_{w,l}.
-inline void g1h_combine(const uint32_t* partials, uint8_t out[96]) {
+inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) {
   G1H::XYZZ acc = G1H::identity();
-  for (int b = 255; b >= 0; b--) {
+  for (int b = 16 * num_windows - 1; b >= 0; b--) {
     acc = G1H::dbl(acc);
     const int w = b >> 4, l = b & 15;
     const uint32_t* base = partials + (size_t)w * 16 * 48;

@@ -29,6 +29,7 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/msm377.h"
 #include "fp64_host.hpp"
@@ -45,8 +46,11 @@ constexpr uint32_t REC_WORDS = 32; // one base record, 128 bytes
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
 constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) blocks of the partition pass
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
-constexpr uint32_t SEG = 64;               // entries per accumulation work item (one thread); longer rows are split (128 measured slower: 2.76 vs 2.60 ms)
-constexpr uint32_t SEG_BINS = SEG + 1;     // work items are counting-sorted by length 0..SEG
+constexpr uint32_t SEG_PLAIN = 64;         // entries per accumulation work item (one thread); longer rows are split.  Plain path: rows
+                                           // are Poisson(32), top window ~219 (128 measured slower there: 2.76 vs 2.60 ms)
+constexpr uint32_t SEG_GLV = 128;          // GLV front end: 2n points per window, rows are Poisson(64) in every window
+constexpr uint32_t SEG_MAX = 128;
+constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by length 0..seg
 constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
 
 // ------------------------------------------------------------------ device helpers ----
@@ -267,6 +271,129 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ 
   if (carry) atomicOr(err, 1);
 }
 
+// ---- GLV front end (the reference lists it as future work, README.md:562) ----
+// phi(x, y) = (BETA x, y) = [LAMBDA](x, y) on G1, LAMBDA = x0^2 - 1 (127 bits).  A scalar
+// k < r splits as k = k1 + k2 LAMBDA with k2 = floor(k / LAMBDA), k1 = k mod LAMBDA, both
+// non-negative and < 2^127, so sum k_i P_i = sum k1_i P_i + sum k2_i phi(P_i): 2n points with
+// 128-bit scalars, i.e. EIGHT 16-bit windows over 2n points instead of sixteen over n.  The
+// bucket additions are the same 16n, but there are half as many buckets to reduce, half as many
+// Horner steps on the host, and no short top window (both halves fill their top window to
+// ~2^14: no 219-entry rows, no split rows).  Everything after this front end is the unchanged
+// pipeline run with wc = 8 window slots over 2n points.
+
+// Record i = P_i, record n + i = phi(P_i).
+__global__ void __launch_bounds__(256) k_convert_bases_glv(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[24];
+  load_words16(raw + i * 24, w, 6);
+  const Fp::El x = Fp::to_mont(Fp::from_words<12>(w));
+  const Fp::El y = Fp::to_mont(Fp::from_words<12>(w + 12));
+  const Fp::El bx = Fp::mul(x, Fp::from_const(G1Consts::BETA));
+  uint32_t o[REC_WORDS];
+#pragma unroll
+  for (int j = 0; j < 13; j++) {
+    o[j] = x.l[j];
+    o[13 + j] = y.l[j];
+  }
+#pragma unroll
+  for (int j = 26; j < 32; j++) o[j] = 0;
+  uint4* dst = reinterpret_cast<uint4*>(bases + i * REC_WORDS);
+#pragma unroll
+  for (int k = 0; k < 8; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+#pragma unroll
+  for (int j = 0; j < 13; j++) o[j] = bx.l[j];
+  dst = reinterpret_cast<uint4*>(bases + (n + i) * REC_WORDS);
+#pragma unroll
+  for (int k = 0; k < 8; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// out[0..NA+NB) = a * b on 32-bit words (schoolbook, carries resolved per row).
+template <int NA, int NB_>
+__device__ __forceinline__ void mul_words(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+#pragma unroll
+  for (int k = 0; k < NA + NB_; k++) out[k] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; i++) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < NB_; j++) {
+      const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+      out[i + j] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+    out[i + NB_] = carry;
+  }
+}
+
+// Eight signed 16-bit digits of a 128-bit value v < 2^127 (top digit stays non-negative).
+// Returns non-zero if the value does not fit (top window reaches 2^15).
+__device__ __forceinline__ uint32_t recode128(const uint32_t* v, uint16_t* __restrict__ digits, size_t stride, size_t col) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (uint32_t win = 0; win < 8; win++) {
+    const uint32_t limb = (v[win >> 1] >> (16 * (win & 1))) & 0xffffu;
+    const uint32_t t = limb + carry;
+    carry = (win < 7 && t >= 32768u) ? 1u : 0u;
+    digits[(size_t)win * stride + col] = (uint16_t)((t + 32768u) & 0xffffu);
+    if (win == 7 && t >= 32768u) return 1u;
+  }
+  return 0u;
+}
+
+// One thread per scalar: k -> (k1, k2) by a Barrett quotient (MU = floor(2^384 / LAMBDA), at
+// most one correction), then the signed digits of k1 into column i and of k2 into column n + i of
+// the 8 x 2n digit matrix.  Scalars outside the GLV range (k2 >= 2^127, i.e. k >~ 2^254) set bit 1
+// of *err: the host then reruns the call on the plain 16-window path.
+__global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n,
+                                                       int* __restrict__ err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k[8];
+  load_words16(scalars + i * 8, k, 2);
+  uint32_t prod[17];
+  mul_words<8, 9>(k, GlvConsts::MU, prod);
+  uint32_t q[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) q[j] = prod[12 + j];  // floor(k MU / 2^384): the quotient or one less
+  uint32_t ql[9];
+  mul_words<5, 4>(q, GlvConsts::LAMBDA, ql);
+  uint32_t rem[5];
+  {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const uint64_t d = (uint64_t)k[j] - ql[j] - borrow;
+      rem[j] = (uint32_t)d;
+      borrow = (uint32_t)(d >> 32) & 1u;
+    }
+  }
+  // rem in [0, 2 LAMBDA): one conditional correction
+  uint32_t sub[5];
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uint64_t d = (uint64_t)rem[j] - (j < 4 ? GlvConsts::LAMBDA[j] : 0u) - borrow;
+    sub[j] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 32) & 1u;
+  }
+  if (!borrow) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) rem[j] = sub[j];
+    uint32_t c = 1;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const uint64_t t = (uint64_t)q[j] + c;
+      q[j] = (uint32_t)t;
+      c = (uint32_t)(t >> 32);
+    }
+  }
+  uint32_t bad = q[4] | rem[4];
+  bad |= recode128(rem, digits, (size_t)2 * n, (size_t)i);
+  bad |= recode128(q, digits, (size_t)2 * n, (size_t)(n + i));
+  if (bad) atomicOr(err, 2);
+}
+
 // ---- per-window counting sort (the reference's transpose, transpose_serial.wgsl:34-76) ----
 //
 // Two-level (MSD) counting sort; every pass touches each (window, point) element once:
@@ -475,7 +602,7 @@ __device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr
 
 // Thread per row, 1024 rows per block: length histogram of its work items (LDS, then one global
 // atomic per bin and block -- the ~60 hot counters serialise, hence the large blocks); rows with more than one item reserve overflow slots and join the split-row list.
-__global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ work_hist,
+__global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ work_hist,
                                                    uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
                                                    uint32_t* __restrict__ split_rows) {
   __shared__ uint32_t lh[SEG_BINS];
@@ -512,7 +639,7 @@ __global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ 
 }
 
 // Thread per row again: claims its slots in the sorted work list.
-__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t* __restrict__ cursor,
+__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ cursor,
                                                       WorkItem* __restrict__ work) {
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t lbase[SEG_BINS];
@@ -543,7 +670,7 @@ template <class CV, int OCC>
 __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
-                                                       const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf) {
+                                                       const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG) {
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= *work_total) return;
   const WorkItem it = work[v];
@@ -589,7 +716,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
 template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
-                                                             const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf) {
+                                                             const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG) {
   const uint32_t count = counters[0];
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
     const uint32_t row = split_rows[i];
@@ -744,7 +871,7 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
 // Quad per split row: bucket += its overflow partials (G1).
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
-                                                                  const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf) {
+                                                                  const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG) {
   const uint32_t count = counters[0];
   const uint32_t q = threadIdx.x & 3;
   for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {
@@ -901,6 +1028,11 @@ struct msm377_ctx {
   bool capture = false;
   bool timing = false;
   uint32_t coop_from = 7;  // first reduction level run with one addition per lane quad (MSM377_COOP_FROM; 15 = never): measured 18-24 -> 13-18 us per level from level 7 on, slower before
+  bool glv = false;        // G1 full-MSM entry points behind the GLV front end (MSM377_GLV=1 / msm377_ctx_set_glv).  Off by default:
+                           // measured 3.67 vs 3.63 ms at n = 2^20 -- the reduction (-0.11 ms) and host tail (-0.10 ms) halve, but the
+                           // accumulation kernel runs 9 % slower (256 MB base table, rows twice as long => coarser work items)
+  bool bases_glv = false;  // the resident base table holds the phi images too (records n..2n)
+  bool last_glv = false;
   bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
   int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
   bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
@@ -1000,14 +1132,19 @@ constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POI
 // the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
 // Nothing here waits for the GPU.
 template <class CV>
-int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc, int slot) {
+int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false) {
+  // GLV front end: n_scalars scalars become 2 n_scalars (point, half-scalar) columns over 8 windows.
+  const uint64_t n = glv ? 2 * n_scalars : n_scalars;
   hipStream_t st = ctx->stream;
   int* d_err = ctx->d_err + slot;
   uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
   HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE);
-    hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, d_err);
+    if (glv)
+      hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n_scalars, d_err);
+    else
+      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, d_err);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -1034,12 +1171,13 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
     HIP_TRY(ctx, hipMemsetAsync(meta, 0, (size_t)(2 * SEG_BINS + 4) * 4, st));
-    hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, work_hist, ctx->d_row_ovf_base, counters,
+    const uint32_t SEG = glv ? SEG_GLV : SEG_PLAIN;
+    hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, SEG, work_hist, ctx->d_row_ovf_base, counters,
                        ctx->d_split_rows);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, cursor, ctx->d_work);
+    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, SEG, cursor, ctx->d_work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->bases_ready, 0));
@@ -1047,21 +1185,21 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
       if (ctx->acc_occ == 4)
         hipLaunchKernelGGL((k_accumulate<CV, 4>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
       else if (ctx->acc_occ == 3)
         hipLaunchKernelGGL((k_accumulate<CV, 3>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf);
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (CV::PT_WORDS == G1Dev::PT_WORDS && ctx->merge_quad)
       hipLaunchKernelGGL(k_merge_split_rows_quad, dim3(4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
-                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf);
+                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
     else
       hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
-                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf);
+                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->capture) {
@@ -1092,6 +1230,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint
   HIP_TRY(ctx, hipEventRecord(ctx->done_ev[slot], st));
   ctx->last_n = n;
   ctx->last_wc = wc;
+  ctx->last_glv = glv;
   ctx->last_is_g1 = CV::PT_WORDS == G1Dev::PT_WORDS;
   return MSM377_OK;
 }
@@ -1114,10 +1253,50 @@ int finish_windows(msm377_ctx* ctx, int slot) {
 }
 
 template <class CV>
-int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc) {
-  int rc = enqueue_windows<CV>(ctx, d_scalars, n, wb, wc, 0);
+int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t wb, uint32_t wc, bool glv = false) {
+  int rc = enqueue_windows<CV>(ctx, d_scalars, n, wb, wc, 0, glv);
   if (rc) return rc;
   return finish_windows(ctx, 0);
+}
+
+constexpr uint32_t GLV_WINDOWS = 8;
+
+// Base conversion for the G1 entry points: with the GLV front end the table also gets phi(P_i).
+int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool glv) {
+  if (!glv) return convert_bases<G1Dev>(ctx, d_raw, n);
+  if (n == 0) return MSM377_OK;
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream2);
+  hipLaunchKernelGGL(k_convert_bases_glv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream2);
+  HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
+  return MSM377_OK;
+}
+
+// Full G1 MSM of n scalars against ctx->d_bases (already converted or being converted on the side
+// stream).  GLV first when enabled and the table holds the phi images; a scalar outside the GLV
+// range (bit 1 of the error word) reruns the call on the plain 16-window path, whose records
+// 0..n-1 of the table are the plain points either way.
+int g1_full_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, bool glv, uint8_t out_xy[96]) {
+  if (glv) {
+    int rc = enqueue_windows<G1Dev>(ctx, d_scalars, n, 0, GLV_WINDOWS, 0, true);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    if ((ctx->h_err[0] & 2) == 0) {
+      rc = finish_windows(ctx, 0);
+      if (rc) return rc;
+      auto t0 = std::chrono::steady_clock::now();
+      g1h_combine(ctx->h_partials, GLV_WINDOWS, out_xy);
+      ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return MSM377_OK;
+    }
+  }
+  int rc = run_windows<G1Dev>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  if (rc) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  g1h_combine(ctx->h_partials, MSM377_NUM_WINDOWS, out_xy);
+  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MSM377_OK;
 }
 
 int check_args(msm377_ctx* ctx, const void* a, const void* b, uint64_t n, bool need_a) {
@@ -1138,12 +1317,7 @@ int check_args(msm377_ctx* ctx, const void* a, const void* b, uint64_t n, bool n
   return MSM377_OK;
 }
 
-int finish_full(msm377_ctx* ctx, uint8_t out_xy[96]) {
-  auto t0 = std::chrono::steady_clock::now();
-  g1h_combine(ctx->h_partials, out_xy);
-  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  return MSM377_OK;
-}
+
 
 }  // namespace
 
@@ -1177,6 +1351,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_REDUCE_FUSED")) ctx->reduce_fused = atoi(e) != 0;
   if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_GLV")) ctx->glv = atoi(e) != 0;
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   const uint64_t cap = max_points;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1185,7 +1360,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
   dalloc((void**)&ctx->d_raw_points, cap * 96);
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
-  dalloc((void**)&ctx->d_bases, cap * REC_WORDS * 4);
+  dalloc((void**)&ctx->d_bases, 2 * cap * REC_WORDS * 4);  // P_i and, for the GLV front end, phi(P_i)
   dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_range_counts, (size_t)NRANGE * MAX_SORT_BLOCKS * 4);  // chunks * wc <= MAX_SORT_BLOCKS
   dalloc((void**)&ctx->d_region_base, (size_t)MSM377_NUM_WINDOWS * (NRANGE + 1) * 4);
@@ -1194,11 +1369,11 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
   dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
-  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG + 1) * sizeof(WorkItem));
+  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_PLAIN + 1) * sizeof(WorkItem));
   dalloc((void**)&ctx->d_work_meta, (size_t)(2 * SEG_BINS + 4) * 4);
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
-  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG + 1) * PT_WORDS * 4);
+  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_PLAIN + 1) * PT_WORDS * 4);
   dalloc((void**)&ctx->d_err, 2 * sizeof(int));
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
@@ -1250,11 +1425,9 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
-  rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
+  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, ctx->glv);
   if (rc) return rc;
-  rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
-  if (rc) return rc;
-  return finish_full(ctx, out_xy);
+  return g1_full_msm(ctx, (const uint32_t*)d_scalars, n, ctx->glv, out_xy);
 }
 
 int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
@@ -1326,10 +1499,11 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
+  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, ctx->glv);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   ctx->bases_n = n;
+  ctx->bases_glv = ctx->glv;
   return MSM377_OK;
 }
 
@@ -1358,9 +1532,7 @@ int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint
     (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream);
     (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream);
   }
-  rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
-  if (rc) return rc;
-  return finish_full(ctx, out_xy);
+  return g1_full_msm(ctx, (const uint32_t*)d_scalars, n, ctx->bases_glv && n == ctx->bases_n, out_xy);
 }
 
 int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy) {
@@ -1377,22 +1549,34 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t* sc = (const uint32_t*)d_scalars;
+  const bool glv = ctx->bases_glv && n == ctx->bases_n;
+  const uint32_t W = glv ? GLV_WINDOWS : MSM377_NUM_WINDOWS;
+  std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
   // Software pipeline over the batch: while the GPU runs MSM b, the host finishes MSM b-1
   // (Horner + inversion on the other slot's partial records).
   for (uint32_t b = 0; b <= batch; b++) {
     if (b < batch) {
-      rc = enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, MSM377_NUM_WINDOWS, (int)(b & 1));
+      rc = enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
       if (rc) return rc;
     }
     if (b > 0) {
       const int slot = (int)((b - 1) & 1);
+      HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
+      if (glv && (ctx->h_err[slot] & 2)) {
+        redo.push_back(b - 1);
+        continue;
+      }
       rc = finish_windows(ctx, slot);
       if (rc) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
       }
-      g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, out_xy + (size_t)96 * (b - 1));
+      g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
     }
+  }
+  for (uint32_t b : redo) {
+    rc = g1_full_msm(ctx, sc + (size_t)b * n * 8, n, false, out_xy + (size_t)96 * b);
+    if (rc) return rc;
   }
   return MSM377_OK;
 }
@@ -1430,7 +1614,7 @@ int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, cons
 
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
-  g1h_combine(reinterpret_cast<const uint32_t*>(partials), out_xy);
+  g1h_combine(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy);
   return MSM377_OK;
 }
 
@@ -1456,7 +1640,7 @@ int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled) {
 
 int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint32_t* row_ptr, uint32_t* val_idx, uint32_t* buckets) {
   if (!ctx) return MSM377_EINVAL;
-  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc || !ctx->last_is_g1) {
+  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc || !ctx->last_is_g1 || ctx->last_glv) {
     ctx->err = "no captured stage data for that window slot";
     return MSM377_ESTATE;
   }
@@ -1481,6 +1665,12 @@ int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint3
 int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]) {
   if (!xyzz || !out_xy) return MSM377_EINVAL;
   g1h_to_wire(g1h_from_device_words(xyzz), out_xy);
+  return MSM377_OK;
+}
+
+int msm377_ctx_set_glv(msm377_ctx* ctx, int enabled) {
+  if (!ctx) return MSM377_EINVAL;
+  ctx->glv = enabled != 0;
   return MSM377_OK;
 }
 

@@ -86,6 +86,7 @@ def load_library():
         "msm377_ctx_set_stage_capture": (i32, [vp, i32]),
         "msm377_g1_read_stage": (i32, [vp, u32, vp, vp, vp, vp]),
         "msm377_g1_xyzz_to_affine": (i32, [vp, vp]),
+        "msm377_ctx_set_glv": (i32, [vp, i32]),
         "msm377_ctx_set_timing": (i32, [vp, i32]),
         "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
     }
@@ -260,6 +261,10 @@ class MsmEngine:
             if v is not None:
                 res[k] = v
         return res
+
+    def set_glv(self, enabled: bool = True):
+        """GLV front end for the G1 full-MSM entry points (off by default = the plain 16-window path)."""
+        self._check(self._lib.msm377_ctx_set_glv(self._ctx, int(bool(enabled))), "msm377_ctx_set_glv")
 
     # -- measurement --
     def set_timing(self, enabled: bool = True):
