@@ -37,6 +37,7 @@ extern "C" {
 #define MSM377_ESCALAR (-3)   /* a scalar overflowed the signed 16-bit recode (final carry) */
 #define MSM377_ENOMEM (-4)    /* device or host allocation failed */
 #define MSM377_ESTATE (-5)    /* call sequence error (e.g. fixed-base MSM before set_bases) */
+#define MSM377_EGLVRANGE (-6) /* GLV window sharding only: a scalar >~ 2^254; repeat with the plain window path */
 
 #define MSM377_NUM_WINDOWS 16          /* ceil(256 / 16): submission.ts:108-109 */
 #define MSM377_WINDOW_BITS 16          /* chunk_size for n >= 2^16: submission.ts:97 */
@@ -91,6 +92,17 @@ int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, cons
  * the ranks) into the final affine result: Horner over the windows, one field inversion.
  * Host-only; needs no context and no device (replaces the CPU tail, submission.ts:290-321). */
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
+
+/* The same sharding behind the GLV front end: MSM377_GLV_WINDOWS = 8 windows over {P_i, phi(P_i)};
+ * win_begin / win_count index those 8.  Returns MSM377_EGLVRANGE when a scalar does not split into
+ * two 127-bit halves (every rank sees the same scalars, so every rank gets the same verdict and the
+ * job repeats on the plain 16-window path).  Halving the windows halves the per-rank fixed costs
+ * (bucket reduction, host tail), which dominate once the additions are spread over several GPUs. */
+#define MSM377_GLV_WINDOWS 8
+int msm377_g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n,
+                                         uint32_t win_begin, uint32_t win_count, uint8_t* partials_out);
+/* Combine `num_windows` gathered partial records (16 plain, 8 GLV).  Host-only. */
+int msm377_g1_combine_window_partials(const uint8_t* partials, uint32_t num_windows, uint8_t out_xy[96]);
 
 /* Synthetic inputs: P_i = [a_i]G, a_i the i-th SplitMix64(seed)
  * output, written in wire format to device memory d_points_out (n x 96 bytes). */

@@ -276,6 +276,35 @@ def test_window_sharding_on_one_gpu(engine, oracle, world):
     assert msm.combine_partials(b"".join(parts)) == util.oracle_msm(oracle, pts, ks)
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 8, 3])
+def test_glv_window_sharding_on_one_gpu(engine, oracle, world):
+    """The multi-GPU data path bench.py uses for N > 1: the 8 GLV windows in rank-sized blocks."""
+    n = 6000
+    pts, ks = seeded_inputs(oracle, n, 89)
+    d_p, d_s = dev(pts), dev(ks)
+    parts = []
+    for r in range(world):
+        b, c = msm.windows_for_rank(r, world, 8)
+        parts.append(engine.glv_window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, b, c))
+    from webgpu_msm_bls12_377_amd.host.engine import combine_partials_bytes
+
+    assert combine_partials_bytes(b"".join(parts), 8) == util.oracle_msm(oracle, pts, ks)
+
+
+def test_glv_window_sharding_reports_out_of_range_scalars(engine, oracle):
+    n = 100
+    pts, ks = seeded_inputs(oracle, n, 90)
+    ks_int = R.decode_scalars(ks)
+    ks_int[3] = (1 << 254) + 7
+    d_p, d_s = dev(pts), dev(R.encode_scalars(ks_int))
+    for b, c in ((0, 8), (2, 3), (7, 1)):  # every shard reaches the same verdict
+        with pytest.raises(msm.MsmError) as e:
+            engine.glv_window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, b, c)
+        assert e.value.code == -6
+    parts = engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, 0, 16)  # the plain fallback
+    assert msm.combine_partials(parts) == R.encode_result(R.msm_naive(R.decode_points(pts), ks_int))
+
+
 def test_sharded_msm_single_rank(engine, oracle):
     from webgpu_msm_bls12_377_amd.host.sharding import sharded_msm
 

@@ -326,19 +326,21 @@ __device__ __forceinline__ void mul_words(const uint32_t* a, const uint32_t* b, 
   }
 }
 
-// Eight signed 16-bit digits of a 128-bit value v < 2^127 (top digit stays non-negative).
-// Returns non-zero if the value does not fit (top window reaches 2^15).
-__device__ __forceinline__ uint32_t recode128(const uint32_t* v, uint16_t* __restrict__ digits, size_t stride, size_t col) {
-  uint32_t carry = 0;
+// Eight signed 16-bit digits of a 128-bit value v < 2^127 (top digit stays non-negative); windows
+// [wb, wb + wc) are written to slots 0..wc-1.  Returns non-zero if the value does not fit (top window
+// reaches 2^15).
+__device__ __forceinline__ uint32_t recode128(const uint32_t* v, uint16_t* __restrict__ digits, size_t stride, size_t col, uint32_t wb,
+                                              uint32_t wc) {
+  uint32_t carry = 0, bad = 0;
 #pragma unroll
   for (uint32_t win = 0; win < 8; win++) {
     const uint32_t limb = (v[win >> 1] >> (16 * (win & 1))) & 0xffffu;
     const uint32_t t = limb + carry;
     carry = (win < 7 && t >= 32768u) ? 1u : 0u;
-    digits[(size_t)win * stride + col] = (uint16_t)((t + 32768u) & 0xffffu);
-    if (win == 7 && t >= 32768u) return 1u;
+    if (win >= wb && win < wb + wc) digits[(size_t)(win - wb) * stride + col] = (uint16_t)((t + 32768u) & 0xffffu);
+    if (win == 7 && t >= 32768u) bad = 1u;
   }
-  return 0u;
+  return bad;
 }
 
 // One thread per scalar: k -> (k1, k2) by a Barrett quotient (MU = floor(2^384 / LAMBDA), at
@@ -346,7 +348,7 @@ __device__ __forceinline__ uint32_t recode128(const uint32_t* v, uint16_t* __res
 // the 8 x 2n digit matrix.  Scalars outside the GLV range (k2 >= 2^127, i.e. k >~ 2^254) set bit 1
 // of *err: the host then reruns the call on the plain 16-window path.
 __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n,
-                                                       int* __restrict__ err) {
+                                                       uint32_t wb, uint32_t wc, int* __restrict__ err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t k[8];
@@ -389,8 +391,8 @@ __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t* __restric
     }
   }
   uint32_t bad = q[4] | rem[4];
-  bad |= recode128(rem, digits, (size_t)2 * n, (size_t)i);
-  bad |= recode128(q, digits, (size_t)2 * n, (size_t)(n + i));
+  bad |= recode128(rem, digits, (size_t)2 * n, (size_t)i, wb, wc);
+  bad |= recode128(q, digits, (size_t)2 * n, (size_t)(n + i), wb, wc);
   if (bad) atomicOr(err, 2);
 }
 
@@ -1142,7 +1144,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE);
     if (glv)
-      hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n_scalars, d_err);
+      hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n_scalars, wb, wc, d_err);
     else
       hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, d_err);
     HIP_TRY(ctx, hipGetLastError());
@@ -1335,6 +1337,7 @@ const char* msm377_strerror(int code) {
     case MSM377_ESCALAR: return "scalar out of range for the signed window recode";
     case MSM377_ENOMEM: return "out of memory";
     case MSM377_ESTATE: return "call sequence error";
+    case MSM377_EGLVRANGE: return "scalar outside the GLV range";
     default: return "unknown error";
   }
 }
@@ -1609,6 +1612,42 @@ int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, cons
   rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count);
   if (rc) return rc;
   memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+  return MSM377_OK;
+}
+
+int msm377_g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin,
+                                         uint32_t win_count, uint8_t* partials_out) {
+  if (!partials_out) return MSM377_EINVAL;
+  int rc = check_args(ctx, d_points, d_scalars, n, true);
+  if (rc) return rc;
+  if (win_count == 0 || win_begin >= GLV_WINDOWS || win_count > GLV_WINDOWS - win_begin) {
+    ctx->err = "GLV window range outside 0..8";
+    return MSM377_EINVAL;
+  }
+  if (n == 0) {
+    memset(partials_out, 0, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+    return MSM377_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->bases_n = 0;
+  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, true);
+  if (rc) return rc;
+  rc = enqueue_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count, 0, true);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+  if (ctx->h_err[0] & 2) {
+    ctx->err = "a scalar is outside the GLV range; use the plain window path";
+    return MSM377_EGLVRANGE;
+  }
+  rc = finish_windows(ctx, 0);
+  if (rc) return rc;
+  memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+  return MSM377_OK;
+}
+
+int msm377_g1_combine_window_partials(const uint8_t* partials, uint32_t num_windows, uint8_t out_xy[96]) {
+  if (!partials || !out_xy || ((uintptr_t)partials & 3) || num_windows == 0 || num_windows > MSM377_NUM_WINDOWS) return MSM377_EINVAL;
+  g1h_combine(reinterpret_cast<const uint32_t*>(partials), (int)num_windows, out_xy);
   return MSM377_OK;
 }
 

@@ -20,7 +20,8 @@ WINDOW_PARTIAL_BYTES = PARTIAL_POINTS * RECORD_POINT_WORDS * 4
 NUM_BUCKETS = 32768
 STAGE_NAMES = ("convert", "decompose", "sort", "accumulate", "reduce", "tail", "accumulate_kernel")
 
-OK, EINVAL, EHIP, ESCALAR, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
+OK, EINVAL, EHIP, ESCALAR, ENOMEM, ESTATE, EGLVRANGE = 0, -1, -2, -3, -4, -5, -6
+GLV_WINDOWS = 8
 
 _LIB = None
 
@@ -79,6 +80,8 @@ def load_library():
         "msm377_g1_msm_fixed_base_batch_device": (i32, [vp, vp, u64, u32, vp]),
         "msm377_g1_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_combine_partials": (i32, [vp, vp]),
+        "msm377_g1_glv_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
+        "msm377_g1_combine_window_partials": (i32, [vp, u32, vp]),
         "msm377_g1_generate_bases_device": (i32, [vp, u64, u64, vp]),
         "msm377_ed_msm": (i32, [vp, u8p, u8p, u64, vp]),
         "msm377_ed_msm_device": (i32, [vp, vp, vp, u64, vp]),
@@ -105,17 +108,17 @@ def _strerror(code: int) -> str:
         return "error"
 
 
-def combine_partials_bytes(partials: bytes) -> bytes:
-    """Host-only Horner + inversion over the 16 windows' partial records
-    (msm377_g1_combine_partials; replaces submission.ts:290-321)."""
-    if len(partials) != NUM_WINDOWS * WINDOW_PARTIAL_BYTES:
-        raise ValueError("expected %d bytes of partials" % (NUM_WINDOWS * WINDOW_PARTIAL_BYTES))
+def combine_partials_bytes(partials: bytes, num_windows: int = NUM_WINDOWS) -> bytes:
+    """Host-only Horner + inversion over the windows' partial records (16 plain, 8 behind the GLV front
+    end; msm377_g1_combine_window_partials; replaces submission.ts:290-321)."""
+    if len(partials) != num_windows * WINDOW_PARTIAL_BYTES:
+        raise ValueError("expected %d bytes of partials" % (num_windows * WINDOW_PARTIAL_BYTES))
     lib = load_library()
     src = (ctypes.c_uint32 * (len(partials) // 4)).from_buffer_copy(partials)
     out = ctypes.create_string_buffer(96)
-    rc = lib.msm377_g1_combine_partials(ctypes.addressof(src), ctypes.addressof(out))
+    rc = lib.msm377_g1_combine_window_partials(ctypes.addressof(src), int(num_windows), ctypes.addressof(out))
     if rc:
-        raise MsmError(rc, "msm377_g1_combine_partials")
+        raise MsmError(rc, "msm377_g1_combine_window_partials")
     return out.raw
 
 
@@ -217,6 +220,15 @@ class MsmEngine:
         self._check(
             self._lib.msm377_g1_window_partials_device(self._ctx, d_points, d_scalars, int(n), int(win_begin), int(win_count), ctypes.addressof(out)),
             "msm377_g1_window_partials_device",
+        )
+        return out.raw[: win_count * WINDOW_PARTIAL_BYTES]
+
+    def glv_window_partials_device(self, d_points: int, d_scalars: int, n: int, win_begin: int, win_count: int) -> bytes:
+        """Same behind the GLV front end (8 windows); raises MsmError(EGLVRANGE) for out-of-range scalars."""
+        out = ctypes.create_string_buffer(max(1, win_count) * WINDOW_PARTIAL_BYTES)
+        self._check(
+            self._lib.msm377_g1_glv_window_partials_device(self._ctx, d_points, d_scalars, int(n), int(win_begin), int(win_count), ctypes.addressof(out)),
+            "msm377_g1_glv_window_partials_device",
         )
         return out.raw[: win_count * WINDOW_PARTIAL_BYTES]
 

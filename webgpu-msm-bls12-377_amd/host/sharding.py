@@ -10,7 +10,7 @@ rank (msm377_g1_combine_partials).
 """
 from typing import Callable, Optional, Tuple
 
-from .engine import NUM_WINDOWS, WINDOW_PARTIAL_BYTES, combine_partials_bytes
+from .engine import GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, combine_partials_bytes
 
 
 def windows_for_rank(rank: int, world_size: int, num_windows: int = NUM_WINDOWS) -> Tuple[int, int]:
@@ -32,14 +32,15 @@ class ShardedMsm:
     """sharded_msm with the exchange buffers allocated once (bench.py, services): a pinned host
     staging tensor, a send tensor and a world_size-slot receive tensor on ``device``."""
 
-    def __init__(self, rank: int, world_size: int, group=None, device=None):
+    def __init__(self, rank: int, world_size: int, group=None, device=None, num_windows: int = NUM_WINDOWS):
         import torch
 
         self.rank, self.world, self.group = rank, world_size, group
-        self.begin, self.count = windows_for_rank(rank, world_size)
-        self.max_count = (NUM_WINDOWS + world_size - 1) // world_size
+        self.num_windows = num_windows  # 16 on the plain path, GLV_WINDOWS = 8 behind the GLV front end
+        self.begin, self.count = windows_for_rank(rank, world_size, num_windows)
+        self.max_count = (num_windows + world_size - 1) // world_size
         self.slot = self.max_count * WINDOW_PARTIAL_BYTES
-        self.counts = [windows_for_rank(r, world_size)[1] for r in range(world_size)]
+        self.counts = [windows_for_rank(r, world_size, num_windows)[1] for r in range(world_size)]
         if world_size > 1:
             pin = device is not None and str(device).startswith("cuda")
             self.send_host = torch.zeros(self.slot, dtype=torch.uint8, pin_memory=pin)
@@ -53,7 +54,7 @@ class ShardedMsm:
         if len(mine) != self.count * WINDOW_PARTIAL_BYTES:
             raise ValueError("partials_fn returned %d bytes for %d windows" % (len(mine), self.count))
         if self.world == 1:
-            return combine_partials_bytes(mine)
+            return combine_partials_bytes(mine, self.num_windows)
         import torch.distributed as dist
 
         if self.count:
@@ -63,7 +64,7 @@ class ShardedMsm:
         self.recv_host.copy_(self.recv_dev)  # synchronising D2H (53 KB at most)
         flat = self.recv_host.numpy()
         parts = [flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts)]
-        return combine_partials_bytes(b"".join(parts))
+        return combine_partials_bytes(b"".join(parts), self.num_windows)
 
 
 def sharded_msm(
