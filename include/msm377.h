@@ -136,13 +136,13 @@ int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint3
 /* Convert one Montgomery XYZZ point (52 words) to the affine wire format (host-only). */
 int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
 
-/* Optional GLV front end for the G1 full-MSM entry points (msm, msm_device, set_bases +
- * fixed_base*): k = k1 + k2 LAMBDA, 8 windows over the 2n points {P_i, phi(P_i)} (SURVEY.md
- * section 8 row f4).  Results are identical; scalars outside the GLV range (>~ 2^254) rerun on the
- * plain 16-window path automatically.  Off by default (it halves the bucket reduction and the
- * host tail but slows the accumulation kernel: 3.67 vs 3.63 ms at n = 2^20); stage read-backs
- * need the plain path; window sharding always uses the plain 16 windows. */
-int msm377_ctx_set_glv(msm377_ctx* ctx, int enabled);
+/* GLV front end for the G1 full-MSM entry points (msm, msm_device, set_bases + fixed_base*):
+ * k = k1 + k2 LAMBDA, 8 windows over the 2n points {P_i, phi(P_i)}.
+ * Results are identical; scalars outside the GLV range (>~ 2^254) rerun on the plain 16-window path
+ * automatically.  mode 0 = never, 1 = always, 2 = auto (default): GLV below ~2^20 points, where the
+ * halved bucket reduction and host tail outweigh its slower accumulation (0.78 vs 1.07 ms at 2^16,
+ * 3.67 vs 3.63 ms at 2^20).  Stage read-backs need the plain path (mode 0). */
+int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 

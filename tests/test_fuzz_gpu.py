@@ -66,12 +66,12 @@ def test_g1_fuzz(engine, oracle, seed):
     pts, ks = fuzz_case(rnd, n, R.R_ORDER, g1_points(oracle))
     pb, sb = R.encode_points(pts), R.encode_scalars(ks)
     exp = util.oracle_msm(oracle, pb, sb)
-    assert engine.msm(pb, sb) == exp
-    engine.set_glv(True)  # the optional GLV front end on the same inputs
     try:
-        assert engine.msm(pb, sb) == exp
+        for mode in (False, True, "auto"):  # plain 16-window path, GLV front end, the default choice
+            engine.set_glv(mode)
+            assert engine.msm(pb, sb) == exp, mode
     finally:
-        engine.set_glv(False)
+        engine.set_glv("auto")
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -75,7 +75,7 @@ def test_stage_parity(engine, oracle):
     n = 5000
     pts, ks = seeded_inputs(oracle, n, 4242)
     engine.set_stage_capture(True)
-    engine.set_glv(False)  # the stage read-backs describe the plain 16-window path (the default)
+    engine.set_glv(False)  # the stage read-backs describe the plain 16-window path
     try:
         res = engine.msm(pts, ks)
         assert res == util.oracle_msm(oracle, pts, ks)
@@ -116,6 +116,7 @@ def test_stage_parity(engine, oracle):
             assert nonempty > 1000
     finally:
         engine.set_stage_capture(False)
+        engine.set_glv("auto")
 
 
 @pytest.mark.parametrize("glv", [True, False])
@@ -131,7 +132,7 @@ def test_glv_and_plain_front_ends(engine, oracle, golden, glv):
             pts, ks = seeded_inputs(oracle, n, 31 + n)
             assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks), n
     finally:
-        engine.set_glv(False)
+        engine.set_glv("auto")
 
 
 def test_scalars_outside_the_glv_range_fall_back(engine, oracle):
@@ -151,7 +152,7 @@ def test_scalars_outside_the_glv_range_fall_back(engine, oracle):
         assert engine.msm_fixed_base(ks2) == exp
         assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
     finally:
-        engine.set_glv(False)
+        engine.set_glv("auto")
 
 
 def test_bucket_boundaries_and_signs(engine, oracle):
@@ -237,7 +238,7 @@ def test_fixed_base_batch_pipeline(engine, oracle, glv):
     sets = [R.encode_scalars(R.rand_scalars(7000 + b, n)) for b in range(batch)]
     engine.set_glv(glv)
     engine.set_bases(pts)
-    engine.set_glv(False)  # the resident table remembers how it was built
+    engine.set_glv("auto")  # the resident table remembers how it was built
     d_s = dev(b"".join(sets))
     got = engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, batch)
     assert got == [util.oracle_msm(oracle, pts, s) for s in sets]

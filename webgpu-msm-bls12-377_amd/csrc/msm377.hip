@@ -1030,9 +1030,11 @@ struct msm377_ctx {
   bool capture = false;
   bool timing = false;
   uint32_t coop_from = 7;  // first reduction level run with one addition per lane quad (MSM377_COOP_FROM; 15 = never): measured 18-24 -> 13-18 us per level from level 7 on, slower before
-  bool glv = false;        // G1 full-MSM entry points behind the GLV front end (MSM377_GLV=1 / msm377_ctx_set_glv).  Off by default:
-                           // measured 3.67 vs 3.63 ms at n = 2^20 -- the reduction (-0.11 ms) and host tail (-0.10 ms) halve, but the
-                           // accumulation kernel runs 9 % slower (256 MB base table, rows twice as long => coarser work items)
+  // GLV front end for the G1 full-MSM entry points: 0 = never, 1 = always, 2 = auto (default): on below
+  // GLV_AUTO_BELOW points.  Measured on one MI355X, plain vs GLV ms per MSM: 2^16 1.07 / 0.78, 2^17 1.28 / 0.96,
+  // 2^18 1.54 / 1.27, 2^19 2.23 / 2.12, 2^20 3.63 / 3.67 -- the halved bucket reduction and host tail are fixed
+  // costs, the 9 % slower accumulation kernel (rows twice as long) scales with n.
+  int glv_mode = 2;
   bool bases_glv = false;  // the resident base table holds the phi images too (records n..2n)
   bool last_glv = false;
   bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
@@ -1262,6 +1264,8 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
 }
 
 constexpr uint32_t GLV_WINDOWS = 8;
+constexpr uint64_t GLV_AUTO_BELOW = 900000;  // auto mode: GLV for n below this (see msm377_ctx::glv_mode)
+inline bool use_glv(const msm377_ctx* ctx, uint64_t n) { return ctx->glv_mode == 1 || (ctx->glv_mode == 2 && n < GLV_AUTO_BELOW); }
 
 // Base conversion for the G1 entry points: with the GLV front end the table also gets phi(P_i).
 int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool glv) {
@@ -1354,7 +1358,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_REDUCE_FUSED")) ctx->reduce_fused = atoi(e) != 0;
   if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
-  if (const char* e = getenv("MSM377_GLV")) ctx->glv = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   const uint64_t cap = max_points;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1428,9 +1432,10 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
-  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, ctx->glv);
+  const bool glv = use_glv(ctx, n);
+  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, glv);
   if (rc) return rc;
-  return g1_full_msm(ctx, (const uint32_t*)d_scalars, n, ctx->glv, out_xy);
+  return g1_full_msm(ctx, (const uint32_t*)d_scalars, n, glv, out_xy);
 }
 
 int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
@@ -1502,11 +1507,12 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, ctx->glv);
+  const bool glv = use_glv(ctx, n);
+  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, glv);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   ctx->bases_n = n;
-  ctx->bases_glv = ctx->glv;
+  ctx->bases_glv = glv;
   return MSM377_OK;
 }
 
@@ -1707,9 +1713,9 @@ int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]) {
   return MSM377_OK;
 }
 
-int msm377_ctx_set_glv(msm377_ctx* ctx, int enabled) {
-  if (!ctx) return MSM377_EINVAL;
-  ctx->glv = enabled != 0;
+int msm377_ctx_set_glv(msm377_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return MSM377_EINVAL;
+  ctx->glv_mode = mode;
   return MSM377_OK;
 }
 

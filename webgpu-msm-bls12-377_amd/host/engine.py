@@ -274,9 +274,11 @@ class MsmEngine:
                 res[k] = v
         return res
 
-    def set_glv(self, enabled: bool = True):
-        """GLV front end for the G1 full-MSM entry points (off by default = the plain 16-window path)."""
-        self._check(self._lib.msm377_ctx_set_glv(self._ctx, int(bool(enabled))), "msm377_ctx_set_glv")
+    def set_glv(self, mode="auto"):
+        """GLV front end for the G1 full-MSM entry points: False/0 = the plain 16-window path, True/1 = always,
+        "auto"/2 = below ~2^20 points (the default)."""
+        m = 2 if mode == "auto" else int(mode)
+        self._check(self._lib.msm377_ctx_set_glv(self._ctx, m), "msm377_ctx_set_glv")
 
     # -- measurement --
     def set_timing(self, enabled: bool = True):
