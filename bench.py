@@ -38,11 +38,15 @@ NUM_WINDOWS = 16
 NUM_BUCKETS = 32768
 
 
-def algorithmic_bytes(n):
+def algorithmic_bytes(n, glv=False):
     """B_alg(n) = 32n + 96n + W*96n + 2*W*2^15*144 + 96 (whole MSM), and the
-    share of the bucket-accumulation launch: W*96n gathered + W*2^15*144 written."""
+    share of the bucket-accumulation launch: W*96n gathered + W*2^15*144 written.  Behind the GLV front end the
+    launch gathers the same 16n coordinates pairs (8 windows x 2n points) and writes 8 windows of buckets."""
     whole = 32 * n + 96 * n + NUM_WINDOWS * 96 * n + 2 * NUM_WINDOWS * NUM_BUCKETS * 144 + 96
-    accumulate = NUM_WINDOWS * 96 * n + NUM_WINDOWS * NUM_BUCKETS * 144
+    if glv:
+        accumulate = 8 * 96 * 2 * n + 8 * NUM_BUCKETS * 144
+    else:
+        accumulate = NUM_WINDOWS * 96 * n + NUM_WINDOWS * NUM_BUCKETS * 144
     return whole, accumulate
 
 
@@ -203,6 +207,7 @@ def main():
     # bucket reduction, host tail -- that dominate once the additions are spread out); scalars outside the GLV range
     # make every rank fall back to the plain 16 windows (all ranks see the same scalars, so they agree).
     use_glv = 1 < world <= 8 and os.environ.get("MSM377_BENCH_GLV", "1") == "1"
+    glv_single = world == 1 and os.environ.get("MSM377_GLV", "2") != "0"  # the engine's default front end (include/msm377.h)
     sharder = ShardedMsm(rank, world, device=xdev)
     sharder_glv = ShardedMsm(rank, world, device=xdev, num_windows=8) if use_glv else None
 
@@ -245,7 +250,8 @@ def main():
 
     out = None
     if rank == 0:
-        whole_bytes, acc_bytes = algorithmic_bytes(n)
+        glv_path = glv_single or (world > 1 and use_glv)
+        whole_bytes, acc_bytes = algorithmic_bytes(n, glv_path)
         nwin = 8 if (world > 1 and use_glv) else NUM_WINDOWS
         _, my_windows = windows_for_rank(rank, world, nwin)
         acc_ms = stages.get("accumulate_kernel", 0.0)  # HIP events around the k_accumulate launch alone
@@ -266,6 +272,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "2^%d BLS12-377 G1 (short Weierstrass) MSM, 16-bit signed windows, inputs resident in HBM" % args.log_n,
+                "front_end": "GLV: 8 windows over the 2n points {P_i, phi(P_i)}" if glv_path else "plain: 16 windows over n points",
                 "points": "P_i=[a_i]G, a_i=SplitMix64(0x377)",
                 "scalars": "uniform < r, SplitMix64(0x5ca1a5)",
                 "parallelism": ("%s windows sharded over %d GPUs, one RCCL all-gather" % ("8 GLV" if use_glv else "16", world)) if world > 1 else "single GPU",

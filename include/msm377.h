@@ -139,9 +139,9 @@ int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
 /* GLV front end for the G1 full-MSM entry points (msm, msm_device, set_bases + fixed_base*):
  * k = k1 + k2 LAMBDA, 8 windows over the 2n points {P_i, phi(P_i)}.
  * Results are identical; scalars outside the GLV range (>~ 2^254) rerun on the plain 16-window path
- * automatically.  mode 0 = never, 1 = always, 2 = auto (default): GLV below ~2^20 points, where the
- * halved bucket reduction and host tail outweigh its slower accumulation (0.78 vs 1.07 ms at 2^16,
- * 3.67 vs 3.63 ms at 2^20).  Stage read-backs need the plain path (mode 0). */
+ * automatically.  mode 0 = never (the plain path), 1 = always, 2 = auto (default; currently GLV at
+ * every size: 1.24 vs 1.39 ms at 2^18, 3.51 vs 3.56 ms at 2^20, 12.4 vs 12.6 ms at 2^22).  Stage
+ * read-backs need the plain path (mode 0). */
 int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
 
 /* ---- measurement ------------------------------------------------------------------------ */

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -46,9 +47,7 @@ constexpr uint32_t REC_WORDS = 32; // one base record, 128 bytes
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
 constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) blocks of the partition pass
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
-constexpr uint32_t SEG_PLAIN = 64;         // entries per accumulation work item (one thread); longer rows are split.  Plain path: rows
-                                           // are Poisson(32), top window ~219 (128 measured slower there: 2.76 vs 2.60 ms)
-constexpr uint32_t SEG_GLV = 128;          // GLV front end: 2n points per window, rows are Poisson(64) in every window
+constexpr uint32_t SEG_MIN = 32;           // entries per accumulation work item (one thread), see auto_seg(); the work-item and overflow buffers are sized for SEG_MIN
 constexpr uint32_t SEG_MAX = 128;
 constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by length 0..seg
 constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
@@ -594,12 +593,31 @@ __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__
 
 struct WorkItem {
   uint32_t row;  // ws * NB + t   (bucket index t <-> key t + 1)
-  uint32_t seg;  // entries [seg * SEG, seg * SEG + SEG) of the row
+  uint32_t seg;  // entries [seg * seglen, seg * seglen + seglen) of the row, see row_split
 };
 
 __device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr, uint32_t row) {
   const uint32_t* rp = row_ptr + (size_t)(row / NB) * RP + (row % NB);
   return rp[2] - rp[1];
+}
+
+// A row of `len` entries becomes `nseg` work items of `seglen` entries (the last one `lastlen`): equal parts of at
+// most SEG entries, so a row just over a multiple of SEG does not leave one full-length chain beside a stub.
+struct RowSplit {
+  uint32_t nseg, seglen, lastlen;
+};
+__device__ __forceinline__ RowSplit row_split(uint32_t len, uint32_t SEG) {
+  RowSplit r;
+  if (len <= SEG) {
+    r.nseg = 1;
+    r.seglen = r.lastlen = len;
+    return r;
+  }
+  const uint32_t parts = (len + SEG - 1) / SEG;
+  r.seglen = (len + parts - 1) / parts;
+  r.nseg = (len + r.seglen - 1) / r.seglen;  // <= parts
+  r.lastlen = len - (r.nseg - 1) * r.seglen;  // 1..seglen
+  return r;
 }
 
 // Thread per row, 1024 rows per block: length histogram of its work items (LDS, then one global
@@ -608,22 +626,35 @@ __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__
                                                    uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
                                                    uint32_t* __restrict__ split_rows) {
   __shared__ uint32_t lh[SEG_BINS];
+  __shared__ uint32_t blk[4];  // split rows, overflow slots of this block; then their bases in the global lists
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
   if (tid < SEG_BINS) lh[tid] = 0;
+  if (tid < 2) blk[tid] = 0;
   __syncthreads();
+  RowSplit sp = {1, 0, 0};
+  uint32_t my_split = 0, my_ovf = 0;
   if (row < rows) {
-    const uint32_t len = row_len(row_ptr, row);
-    const uint32_t nfull = len / SEG, rem = len % SEG;
-    if (nfull) atomicAdd(&lh[SEG], nfull);
-    if (rem || len == 0) atomicAdd(&lh[rem], 1u);
-    const uint32_t nseg = nfull + ((rem || len == 0) ? 1u : 0u);
-    if (nseg > 1) {
-      row_ovf_base[row] = atomicAdd(&counters[1], nseg - 1);
-      split_rows[atomicAdd(&counters[0], 1u)] = row;
+    sp = row_split(row_len(row_ptr, row), SEG);
+    atomicAdd(&lh[sp.lastlen], 1u);
+    if (sp.nseg > 1) {
+      atomicAdd(&lh[sp.seglen], sp.nseg - 1);
+      my_split = atomicAdd(&blk[0], 1u);
+      my_ovf = atomicAdd(&blk[1], sp.nseg - 1);
     }
   }
   __syncthreads();
   if (tid < SEG_BINS && lh[tid]) atomicAdd(&work_hist[tid], lh[tid]);
+  // One pair of global atomics per block (a row's slots stay contiguous, a block's rows stay together in the
+  // split-row list, so the merge pass touches neighbouring buckets).
+  if (tid == 0 && blk[0]) {
+    blk[2] = atomicAdd(&counters[0], blk[0]);
+    blk[3] = atomicAdd(&counters[1], blk[1]);
+  }
+  __syncthreads();
+  if (sp.nseg > 1) {
+    row_ovf_base[row] = blk[3] + my_ovf;
+    split_rows[blk[2] + my_split] = row;
+  }
 }
 
 // One block (SEG_BINS <= 256): cursor[b] = number of items longer than b (descending order), total item count.
@@ -648,22 +679,19 @@ __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restric
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
   if (tid < SEG_BINS) lh[tid] = 0;
   __syncthreads();
-  uint32_t nfull = 0, rem = 0, rank_full = 0, rank_rem = 0;
-  bool has_rem = false;
+  RowSplit sp = {0, 0, 0};
+  uint32_t rank_full = 0, rank_last = 0;
   if (row < rows) {
-    const uint32_t len = row_len(row_ptr, row);
-    nfull = len / SEG;
-    rem = len % SEG;
-    has_rem = rem || len == 0;
-    if (nfull) rank_full = atomicAdd(&lh[SEG], nfull);
-    if (has_rem) rank_rem = atomicAdd(&lh[rem], 1u);
+    sp = row_split(row_len(row_ptr, row), SEG);
+    if (sp.nseg > 1) rank_full = atomicAdd(&lh[sp.seglen], sp.nseg - 1);
+    rank_last = atomicAdd(&lh[sp.lastlen], 1u);
   }
   __syncthreads();
   if (tid < SEG_BINS && lh[tid]) lbase[tid] = atomicAdd(&cursor[tid], lh[tid]);
   __syncthreads();
   if (row < rows) {
-    for (uint32_t s = 0; s < nfull; s++) work[lbase[SEG] + rank_full + s] = WorkItem{row, s};
-    if (has_rem) work[lbase[rem] + rank_rem] = WorkItem{row, nfull};
+    for (uint32_t s = 0; s + 1 < sp.nseg; s++) work[lbase[sp.seglen] + rank_full + s] = WorkItem{row, s};
+    work[lbase[sp.lastlen] + rank_last] = WorkItem{row, sp.nseg - 1};
   }
 }
 
@@ -679,9 +707,10 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   const uint32_t ws = it.row / NB, t = it.row % NB;
   const uint32_t* rp = row_ptr + (size_t)ws * RP;
   const uint32_t* vi = val_idx + (size_t)ws * n;
-  const uint32_t row_end = rp[t + 2];
-  uint32_t k = rp[t + 1] + it.seg * SEG;
-  const uint32_t end = (row_end - k > SEG) ? k + SEG : row_end;
+  const uint32_t row_beg = rp[t + 1], row_end = rp[t + 2];
+  const uint32_t seglen = row_split(row_end - row_beg, SEG).seglen;
+  uint32_t k = row_beg + it.seg * seglen;
+  const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
   typename CV::Pt acc = CV::identity();
   if (k < end) {
     // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
@@ -723,7 +752,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
     const uint32_t row = split_rows[i];
     const uint32_t len = row_len(row_ptr, row);
-    const uint32_t nseg = (len + SEG - 1) / SEG;
+    const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row / NB, t = row % NB;
     typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
     const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::PT_WORDS;
@@ -879,7 +908,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
   for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {
     const uint32_t row = split_rows[i];
     const uint32_t len = row_len(row_ptr, row);
-    const uint32_t nseg = (len + SEG - 1) / SEG;
+    const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row / NB, t = row % NB;
     G1XYZZ acc = load_bucket<G1Dev>(buckets, ws, t);
     const uint32_t* src = ovf + (size_t)row_ovf_base[row] * G1Dev::PT_WORDS;
@@ -1030,14 +1059,17 @@ struct msm377_ctx {
   bool capture = false;
   bool timing = false;
   uint32_t coop_from = 7;  // first reduction level run with one addition per lane quad (MSM377_COOP_FROM; 15 = never): measured 18-24 -> 13-18 us per level from level 7 on, slower before
-  // GLV front end for the G1 full-MSM entry points: 0 = never, 1 = always, 2 = auto (default): on below
-  // GLV_AUTO_BELOW points.  Measured on one MI355X, plain vs GLV ms per MSM: 2^16 1.07 / 0.78, 2^17 1.28 / 0.96,
-  // 2^18 1.54 / 1.27, 2^19 2.23 / 2.12, 2^20 3.63 / 3.67 -- the halved bucket reduction and host tail are fixed
-  // costs, the 9 % slower accumulation kernel (rows twice as long) scales with n.
+  // GLV front end for the G1 full-MSM entry points: 0 = never, 1 = always, 2 = auto (default).  Interleaved A/B
+  // on one MI355X (tools/ab_knobs.py), plain vs GLV ms per MSM: 2^18 1.39 / 1.24, 2^19 2.08 / 2.00, 2^20 3.56 / 3.51,
+  // 2^21 6.62 / 6.65, 2^22 12.56 / 12.39 -- the halved bucket reduction and host tail are fixed costs, the
+  // accumulation kernel runs at the same rate once the work items are sized by auto_seg().  Auto therefore takes
+  // the GLV path at every size; scalars outside its range rerun on the plain path.
   int glv_mode = 2;
   bool bases_glv = false;  // the resident base table holds the phi images too (records n..2n)
   bool last_glv = false;
+  bool merge_full_grid = true;  // MSM377_MERGE_FULL_GRID=0: fixed 64-workgroup sweep of the split-row list (A/B knob)
   bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
+  uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
   int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
   bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
   hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
@@ -1130,6 +1162,20 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
   return MSM377_OK;
 }
 
+// Entries per accumulation work item.  The kernel is a list of ~(rows + entries / SEG) independent serial chains
+// handed out longest-first to 2048 resident waves: too few, too long chains leave the last round of waves
+// half-empty (GLV at 2^20 with SEG 96: 4400 waves, 2.83 ms; SEG 64: 6100 waves, 2.47 ms), too short ones pay an
+// overflow record and a merge addition per extra chain.  Interleaved A/B runs (tools/ab_knobs.py) put the best
+// length near entries / 2^18 for both front ends (entries = windows in this call x points per window): 32 at
+// n = 2^19, 64 at 2^20, 96-128 at 2^21; a rank that owns one or two windows of a sharded MSM gets short chains,
+// so that its few rows still fill the GPU.
+uint32_t auto_seg(const msm377_ctx* ctx, uint64_t entries, bool glv) {
+  const uint32_t forced = glv ? ctx->seg_glv : ctx->seg_plain;
+  if (forced) return forced;
+  const uint64_t s = ((entries >> 18) + 7) & ~7ull;
+  return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, SEG_MIN), SEG_MAX);
+}
+
 constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot
 
 // Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
@@ -1175,7 +1221,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
     HIP_TRY(ctx, hipMemsetAsync(meta, 0, (size_t)(2 * SEG_BINS + 4) * 4, st));
-    const uint32_t SEG = glv ? SEG_GLV : SEG_PLAIN;
+    const uint32_t SEG = auto_seg(ctx, (uint64_t)wc * n, glv);
     hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, SEG, work_hist, ctx->d_row_ovf_base, counters,
                        ctx->d_split_rows);
     HIP_TRY(ctx, hipGetLastError());
@@ -1199,10 +1245,10 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     }
     HIP_TRY(ctx, hipGetLastError());
     if (CV::PT_WORDS == G1Dev::PT_WORDS && ctx->merge_quad)
-      hipLaunchKernelGGL(k_merge_split_rows_quad, dim3(4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
+      hipLaunchKernelGGL(k_merge_split_rows_quad, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
                          ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
     else
-      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
+      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? rows / 256 : MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
                          ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1264,8 +1310,7 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
 }
 
 constexpr uint32_t GLV_WINDOWS = 8;
-constexpr uint64_t GLV_AUTO_BELOW = 900000;  // auto mode: GLV for n below this (see msm377_ctx::glv_mode)
-inline bool use_glv(const msm377_ctx* ctx, uint64_t n) { return ctx->glv_mode == 1 || (ctx->glv_mode == 2 && n < GLV_AUTO_BELOW); }
+inline bool use_glv(const msm377_ctx* ctx, uint64_t) { return ctx->glv_mode != 0; }  // see msm377_ctx::glv_mode
 
 // Base conversion for the G1 entry points: with the GLV front end the table also gets phi(P_i).
 int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool glv) {
@@ -1359,6 +1404,9 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
+  if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
+  if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   const uint64_t cap = max_points;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1376,11 +1424,11 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
   dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
-  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_PLAIN + 1) * sizeof(WorkItem));
+  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_MIN + 1) * sizeof(WorkItem));
   dalloc((void**)&ctx->d_work_meta, (size_t)(2 * SEG_BINS + 4) * 4);
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
-  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_PLAIN + 1) * PT_WORDS * 4);
+  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 1) * PT_WORDS * 4);
   dalloc((void**)&ctx->d_err, 2 * sizeof(int));
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;

@@ -276,7 +276,7 @@ class MsmEngine:
 
     def set_glv(self, mode="auto"):
         """GLV front end for the G1 full-MSM entry points: False/0 = the plain 16-window path, True/1 = always,
-        "auto"/2 = below ~2^20 points (the default)."""
+        "auto"/2 = the library's choice (the default; currently GLV at every size)."""
         m = 2 if mode == "auto" else int(mode)
         self._check(self._lib.msm377_ctx_set_glv(self._ctx, m), "msm377_ctx_set_glv")
 
