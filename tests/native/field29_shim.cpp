@@ -56,6 +56,23 @@ void shim_g1_madd(const uint32_t* acc52, const uint32_t* q24, uint32_t* out52) {
   q.y = load(q24 + 12);
   store_xyzz(g1_madd(load_xyzz(acc52), q), out52);
 }
+// acc += (+-) q_k for k = 0..count-1, the accumulator fed back in its stored (lazy) form like k_accumulate does
+void shim_g1_madd_chain(const uint32_t* acc52, const uint32_t* q24s, const uint8_t* negs, uint32_t count, uint32_t* out52) {
+  G1XYZZ acc = load_xyzz(acc52);
+  for (uint32_t k = 0; k < count; k++) {
+    G1Affine q;
+    q.x = load(q24s + 24 * k);
+    q.y = load(q24s + 24 * k + 12);
+    acc = g1_madd(acc, q, negs[k] != 0);
+  }
+  store_xyzz(acc, out52);
+}
+// tree of general additions over stored (lazy) points: out = sum of count points
+void shim_g1_add_chain(const uint32_t* pts52, uint32_t count, uint32_t* out52) {
+  G1XYZZ acc = load_xyzz(pts52);
+  for (uint32_t k = 1; k < count; k++) acc = g1_add(load_xyzz(pts52 + 52 * k), acc);
+  store_xyzz(acc, out52);
+}
 void shim_g1_add(const uint32_t* a52, const uint32_t* b52, uint32_t* out52) { store_xyzz(g1_add(load_xyzz(a52), load_xyzz(b52)), out52); }
 void shim_g1_dbl(const uint32_t* a52, uint32_t* out52) { store_xyzz(g1_dbl(load_xyzz(a52)), out52); }
 // the 64-bit host-tail field through the same curve template

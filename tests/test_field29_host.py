@@ -111,3 +111,45 @@ def test_curve_ops_including_special_cases(shim):
         assert w.raw == R.encode_result(R.add(a, b))
     shim.shim_g1_dbl(xyzz_buf(None), out)
     assert util.affine_from_xyzz_words(list(out)) is None
+
+
+def test_lazy_accumulation_chains(shim):
+    """k_accumulate's inner loop on the host: the accumulator stays in its stored form (X below 5p, not reduced
+    mod p -- csrc/g1_xyzz.hpp madd_lz) across mixed additions with signs, repeated and opposite points, then the
+    partial sums are added with the general formula.  Stored limbs must stay carry-normalised."""
+    rnd = random.Random(2024)
+    pts = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(10)]
+    partials, expected_total = [], None
+    for trial in range(12):
+        count = rnd.choice([1, 2, 5, 40])
+        seq = [rnd.choice(pts) for _ in range(count)]
+        negs = [rnd.randrange(2) for _ in range(count)]
+        if trial == 3:  # P, P, -P, -P ...: doubling and cancellation inside a chain
+            seq, negs = [pts[0]] * 6, [0, 0, 1, 1, 1, 0]
+        start = rnd.choice([None, pts[1]])
+        z = rnd.randrange(1, R.P)
+        q = (ctypes.c_uint32 * (24 * count))(*[w for pt in seq for w in xy24(pt)])
+        out = (ctypes.c_uint32 * 52)()
+        shim.shim_g1_madd_chain(xyzz_buf(start, z), q, (ctypes.c_uint8 * count)(*negs), count, out)
+        exp = start
+        for pt, ng in zip(seq, negs):
+            exp = R.add(exp, R.neg(pt) if ng else pt)
+        assert util.affine_from_xyzz_words(list(out)) == exp, trial
+        words = list(out)
+        for c in range(4):
+            assert all(w < (1 << 29) for w in words[13 * c : 13 * c + 12]), "limbs 0..11 carry-normalised"
+        assert sum(int(w) << (29 * i) for i, w in enumerate(words[0:13])) < 5 * R.P + (1 << 354)
+        for c in range(1, 4):
+            assert sum(int(w) << (29 * i) for i, w in enumerate(words[13 * c : 13 * c + 13])) < R.P + (1 << 354)
+        partials.append(words)
+        expected_total = R.add(expected_total, exp)
+    flat = (ctypes.c_uint32 * (52 * len(partials)))(*[w for p in partials for w in p])
+    out = (ctypes.c_uint32 * 52)()
+    shim.shim_g1_add_chain(flat, len(partials), out)
+    assert util.affine_from_xyzz_words(list(out)) == expected_total
+
+
+def test_lazy_bounds_proof():
+    """tools/check_lazy_bounds.py: interval replay of the lazy formulas -- no 64-bit column can overflow, no limb
+    of a limb-wise subtraction can go negative, results meet the storage invariant."""
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "check_lazy_bounds.py")])

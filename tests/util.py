@@ -13,7 +13,7 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libmsm_oracle.so")
 
 LB = 29
 LMASK = (1 << LB) - 1
-R29 = 1 << (LB * 13)  # device Montgomery radix for Fp
+R29 = 1 << (LB * 14)  # device Montgomery radix for Fp (14 reduction steps over 13 limbs, csrc/field29.hpp)
 
 
 def load_oracle():
@@ -108,7 +108,7 @@ def load_golden():
 
 # ---- device formats ----
 def to_limbs29_mont(v: int):
-    """canonical residue -> 13 x 29-bit limbs of v * 2^377 mod p (csrc/field29.hpp format)."""
+    """canonical residue -> 13 x 29-bit limbs of v * 2^406 mod p (csrc/field29.hpp format)."""
     m = (v * R29) % R.P
     return [(m >> (LB * i)) & LMASK for i in range(13)]
 

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Worst-case bounds of the lazy G1 formulas (csrc/g1_xyzz.hpp madd_lz / add_lz, msm377.hip g1_add_quad).
+
+Every field value is tracked as (limb upper bounds[13], value upper bound, value lower bound); the script replays
+the formulas on those intervals and asserts, for every product, that no 64-bit column accumulator of
+csrc/field29.hpp (mul_lz, sqr_lz, mul_add_mul_lz) can overflow, for every add_kp_sub that no limb can go negative,
+and that the results satisfy the storage invariant the next addition assumes:
+
+    X: N-form, value < 5p + 2^354        Y, ZZ, ZZZ: N-form, value < p + 2^354
+
+Run by tests/test_lazy_bounds.py; exits non-zero on any violation.
+"""
+import os
+import re
+import sys
+
+P = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+LB, N, RS = 29, 13, 14
+BETA = 1 << LB
+MASK = BETA - 1
+E = 1 << 354
+MOD = [(P >> (LB * j)) & MASK for j in range(N)]
+
+
+def load_consts():
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = open(os.path.join(here, "..", "webgpu-msm-bls12-377_amd", "csrc", "consts_gen.hpp")).read()
+    g1 = text[text.index("struct G1Consts") : text.index("struct GlvConsts")]
+    out = {}
+    for name in ("KP2", "KP6", "KP4W3", "MOD", "MOD2", "MOD4"):
+        m = re.search(r"uint32_t %s\[13\] = \{([^}]*)\}" % name, g1)
+        out[name] = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+    assert "RS = 14" in g1
+    return out
+
+
+K = load_consts()
+assert K["MOD"] == MOD
+for name, k in (("KP2", 2), ("KP6", 6), ("KP4W3", 4), ("MOD2", 2), ("MOD4", 4)):
+    assert sum(x << (LB * j) for j, x in enumerate(K[name])) == k * P, name
+
+
+class V:
+    """Interval model of one 13-limb value."""
+
+    def __init__(self, limbs, hi, lo=0, name=""):
+        self.limbs, self.hi, self.lo, self.name = list(limbs), hi, lo, name
+        assert all(0 <= x < (1 << 32) for x in self.limbs), (name, [hex(x) for x in self.limbs])
+
+    @property
+    def normalised(self):
+        return all(x <= MASK for x in self.limbs[:-1])
+
+
+def nform(hi, lo=0, name=""):
+    """Carry-normalised value below hi: limbs 0..11 <= 2^29 - 1, top limb <= (hi - 1) >> 348."""
+    return V([MASK] * (N - 1) + [(hi - 1) >> (LB * (N - 1))], hi, lo, name)
+
+
+def m1(name=""):
+    return nform(P + E, 0, name)
+
+
+def check_columns(pairs, what):
+    """pairs: list of (a, b) products accumulated into the same columns, plus RS reduction rows."""
+    worst = 0
+    for k in range(2 * N):
+        s = 0
+        for a, b in pairs:
+            for i in range(N):
+                j = k - i
+                if 0 <= j < N:
+                    s += a.limbs[i] * b.limbs[j]
+        for i in range(RS):  # q_i * MOD[j], q_i <= 2^29 - 1; j = 0 is the implicit + q
+            j = k - i
+            if 0 <= j < N:
+                s += MASK * MOD[j]
+        s += 1 << 40  # carry from the column below (a column is < 2^64, >> 29 leaves < 2^35)
+        worst = max(worst, s)
+    assert worst < (1 << 64), "%s: column sum 2^%.2f" % (what, __import__("math").log2(worst))
+    return worst
+
+
+def product_value(pairs):
+    return sum(a.hi * b.hi for a, b in pairs) // (1 << (LB * RS)) + 1 + P
+
+
+def mul_lz(a, b, name):
+    check_columns([(a, b)], name)
+    hi = product_value([(a, b)])
+    assert hi <= P + E, (name, hi / P)
+    return m1(name)
+
+
+def sqr_lz(a, name):
+    assert a.normalised, name  # 2 * a_i must fit 32 bits for i <= 11
+    return mul_lz(a, a, name)
+
+
+def mul_add_mul_lz(a, b, e, d, name):
+    check_columns([(a, b), (e, d)], name)
+    hi = product_value([(a, b), (e, d)])
+    assert hi <= P + E, (name, hi / P)
+    return m1(name)
+
+
+def add_kp_sub(a, kname, k, b, name, b2=None):
+    """a + K - b (- 2 b2): limb-wise; K = k p."""
+    Kl = K[kname]
+    limbs = []
+    for j in range(N):
+        sub = b.limbs[j] + (2 * b2.limbs[j] if b2 else 0)
+        assert Kl[j] >= sub, "%s: limb %d of %s (%#x) below the subtrahend bound %#x" % (name, j, kname, Kl[j], sub)
+        limbs.append(a.limbs[j] + Kl[j])
+    sub_hi = b.hi + (2 * b2.hi if b2 else 0)
+    sub_lo = b.lo + (2 * b2.lo if b2 else 0)
+    return V(limbs, a.hi + k * P - sub_lo, max(0, a.lo + k * P - sub_hi), name)
+
+
+def kp_sub(kname, k, b, name):
+    Kl = K[kname]
+    for j in range(N):
+        assert Kl[j] >= b.limbs[j], (name, j)
+    return V(list(Kl), k * P - b.lo + 1, max(0, k * P - b.hi), name)
+
+
+def norm(a, name):
+    assert a.hi < (1 << 380), (name, a.hi / P)
+    return nform(a.hi, a.lo, name)
+
+
+def canon_ok(a, name):
+    assert a.normalised and a.hi <= 8 * P, (name, a.hi / P)
+
+
+def point_formula(x1, y1, zz1, zzz1, u_in, s_in, kp_p, kname_p, p_mults, tag):
+    """Shared tail of madd_lz (u_in = U2, X1 = x1, ...) and add_lz (x1 = U1, y1 = S1)."""
+    p = norm(add_kp_sub(u_in, kname_p, kp_p, x1, tag + " P"), tag + " P")
+    r = norm(add_kp_sub(s_in, "KP2", 2, y1, tag + " R"), tag + " R")
+    # P = 0 mod p <=> P in {p, .., p_mults p}: the guard (P.l[0] - 1) < p_mults must cover the whole range
+    assert p.lo > 0 and p.hi <= (p_mults + 1) * P and r.lo > 0, (tag, p.lo, p.hi / P)
+    canon_ok(p, tag + " canon(P)")
+    canon_ok(r, tag + " canon(R)")
+    pp = sqr_lz(p, tag + " PP")
+    ppp = mul_lz(p, pp, tag + " PPP")
+    qq = mul_lz(x1, pp, tag + " Q")
+    rr = sqr_lz(r, tag + " RR")
+    x3 = norm(add_kp_sub(rr, "KP4W3", 4, ppp, tag + " X3", b2=qq), tag + " X3")
+    assert x3.hi <= 5 * P + E, (tag, x3.hi / P)
+    d = norm(add_kp_sub(qq, "KP6", 6, x3, tag + " D"), tag + " D")
+    y3 = mul_add_mul_lz(r, d, kp_sub("KP2", 2, y1, tag + " -Y1"), ppp, tag + " Y3")
+    return x3, y3, pp, ppp, r, d, qq
+
+
+def main():
+    canonical = nform(P, 0, "canonical")
+    X1 = nform(5 * P + E, 0, "X1")
+    Y1, ZZ1, ZZZ1 = m1("Y1"), m1("ZZ1"), m1("ZZZ1")
+
+    # ---- madd_lz ----
+    u2 = mul_lz(canonical, ZZ1, "madd U2")
+    qy = kp_sub("KP2", 2, canonical, "madd -qy")  # negated base y (lazy); the plain one is canonical
+    s2 = mul_lz(qy, ZZZ1, "madd S2")
+    x3, y3, pp, ppp, *_ = point_formula(X1, Y1, ZZ1, ZZZ1, u2, s2, 6, "KP6", 7, "madd")
+    mul_lz(ZZ1, pp, "madd ZZ3")
+    mul_lz(ZZZ1, ppp, "madd ZZZ3")
+
+    # ---- add_lz (thread) ----
+    X2 = nform(5 * P + E, 0, "X2")
+    u1 = mul_lz(X1, ZZ1, "add U1")
+    u2 = mul_lz(X2, ZZ1, "add U2")
+    s1 = mul_lz(Y1, ZZZ1, "add S1")
+    s2 = mul_lz(Y1, ZZZ1, "add S2")
+    x3, y3, pp, ppp, r, d, qq = point_formula(u1, s1, ZZ1, ZZZ1, u2, s2, 2, "KP2", 3, "add")
+    mul_lz(mul_lz(ZZ1, ZZ1, "add ZZ1ZZ2"), pp, "add ZZ3")
+    mul_lz(mul_lz(ZZZ1, ZZZ1, "add ZZZ1ZZZ2"), ppp, "add ZZZ3")
+
+    # ---- g1_add_quad: round 2 squares P and R through mul_lz, round 4 forms Y3 from two separate products ----
+    mul_lz(r, r, "quad RR")
+    a = mul_lz(r, d, "quad R*D")
+    b = mul_lz(s1, ppp, "quad S1*PPP")
+    y = norm(add_kp_sub(a, "KP2", 2, b, "quad Y3"), "quad Y3")
+    canon_ok(y, "quad canon(Y3)")
+
+    # canonical operations on stored (lazy) coordinates: mul() = reduce_once(mul_lz()) needs mul_lz < 2p
+    mul_lz(X1, canonical, "gather X*TO64")
+    print("lazy bounds OK")
+
+
+if __name__ == "__main__":
+    main()

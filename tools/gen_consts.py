@@ -10,8 +10,10 @@ Sources of the numbers (reference, read as text):
 
 Output: two structs of static constexpr tables, G1Consts (Fp) and EdConsts (Fq).
 Device format: little-endian 29-bit limbs in u32 words.  Fp: 13 limbs, Montgomery
-radix R = 2^377.  Fq: 9 limbs, Montgomery radix R = 2^261.  Both moduli are
-= 1 mod 2^29, so -p^-1 mod 2^29 = 2^29 - 1 and the Montgomery quotient digit is
+radix R = 2^406 (14 reduction steps over 13-limb operands: a product of two values
+below 2^380 comes out below p + 2^354, so the hot formulas need no conditional
+subtractions -- see field29.hpp).  Fq: 9 limbs, Montgomery radix R = 2^261.  Both moduli
+are = 1 mod 2^29, so -p^-1 mod 2^29 = 2^29 - 1 and the Montgomery quotient digit is
 just (-t0) mod 2^29 (no multiplication).
 """
 import os
@@ -32,16 +34,39 @@ def limbs(v, n):
     return [(v >> (LB * i)) & MASK for i in range(n)]
 
 
+def limbs_top(v, n):
+    return [(v >> (LB * i)) & MASK for i in range(n - 1)] + [v >> (LB * (n - 1))]
+
+
 def arr(name, v, n):
     body = ", ".join("0x%08xu" % x for x in limbs(v, n))
     return "static constexpr uint32_t %s[%d] = {%s};\n" % (name, n, body)
 
 
-def emit(ns, mod, n, extra):
-    R = 1 << (LB * n)
+def redundant(v, n, w):
+    """k*p written with every limb but the top one raised by w*2^29 (borrowed from the limb above), so that
+    a_j + c_j - (up to w limbs b_j < 2^29) never goes negative limb by limb."""
+    m = limbs_top(v, n)
+    c = [m[0] + w * (1 << LB)] + [m[j] + w * (1 << LB) - w for j in range(1, n - 1)] + [m[n - 1] - w]
+    assert sum(x << (LB * j) for j, x in enumerate(c)) == v and all(0 <= x < (1 << 32) for x in c)
+    assert all(x >= w * MASK for x in c[:-1])
+    return c
+
+
+def emit(ns, mod, n, extra, rs=None, lazy=False):
+    rs = rs or n
+    R = 1 << (LB * rs)
     assert mod & MASK == 1
     out = "struct %s {\n" % ns
     out += "static constexpr int NL = %d;\n" % n
+    out += "static constexpr int RS = %d;  // Montgomery reduction steps: R = 2^(29 RS)\n" % rs
+    if lazy:
+        for name, k, w in (("KP2", 2, 1), ("KP6", 6, 1), ("KP4W3", 4, 3)):
+            body = ", ".join("0x%08xu" % x for x in redundant(k * mod, n, w))
+            out += "static constexpr uint32_t %s[%d] = {%s};  // %d p, limbs raised by %d * 2^29\n" % (name, n, body, k, w)
+        for name, k in (("MOD2", 2), ("MOD4", 4)):
+            body = ", ".join("0x%08xu" % x for x in limbs_top(k * mod, n))
+            out += "static constexpr uint32_t %s[%d] = {%s};  // %d p, top limb unbounded\n" % (name, n, body, k)
     out += arr("MOD", mod, n)
     out += arr("ONE", R % mod, n)          # Montgomery form of 1
     out += arr("R2", (R * R) % mod, n)     # to-Montgomery multiplier
@@ -58,8 +83,8 @@ def emit(ns, mod, n, extra):
 
 
 def emit64(ns, mod, n, n29, extra=None):
-    """Host-tail field constants: 64-bit words, Montgomery radix 2^(64n); n29 = limb count of the
-    device format of the same field."""
+    """Host-tail field constants: 64-bit words, Montgomery radix 2^(64n); n29 = Montgomery reduction
+    steps (radix 2^(29 n29)) of the device format of the same field."""
     R = 1 << (64 * n)
 
     def arr64(name, v):
@@ -128,10 +153,10 @@ def main():
     dst = os.path.join(here, "..", "webgpu-msm-bls12-377_amd", "csrc", "consts_gen.hpp")
     s = "// GENERATED by tools/gen_consts.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\n"
     s += "namespace msm377 {\n\n"
-    s += emit("G1Consts", P, 13, {"GEN_X": GX, "GEN_Y": GY, "B3": 3, "BETA": GLV_BETA})
+    s += emit("G1Consts", P, 13, {"GEN_X": GX, "GEN_Y": GY, "B3": 3, "BETA": GLV_BETA}, rs=14, lazy=True)
     s += emit_glv()
     s += emit("EdConsts", Q, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D, "GEN_X": ED_GX, "GEN_Y": ED_GY})
-    s += emit64("G1Consts64", P, 6, 13)
+    s += emit64("G1Consts64", P, 6, 14)
     s += emit64("EdConsts64", Q, 4, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D})
     s += "}  // namespace msm377\n"
     with open(dst, "w") as f:

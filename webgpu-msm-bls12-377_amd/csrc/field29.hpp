@@ -11,10 +11,12 @@
 // 12 q*p terms of < 2^58 each, so every column fits a 64-bit accumulator and the whole
 // product is a carry-free stream of v_mad_u64_u32; carries are resolved once at the end.
 // Both moduli are = 1 (mod 2^29), so the Montgomery quotient digit is (-t0) mod 2^29 and
-// the q*p[0] term is a plain add: a product costs N*N + N*(N-1) multiply-adds.
+// the q*p[0] term is a plain add: a product costs N*N + RS*(N-1) multiply-adds (RS = reduction
+// steps: N for Fq, N + 1 for Fp -- see "Montgomery products" below).
 //
 // Unlike the reference (fr_sub(a,a) = p, conditional_reduce keeps p), every value
-// returned here is canonical: 0 <= x < p, limbs < 2^29.
+// returned by the plain operations (add, sub, mul, ...) is canonical: 0 <= x < p, limbs < 2^29.
+// The *_lz operations used inside the G1 point formulas trade that for fewer instructions.
 #pragma once
 #include <stdint.h>
 
@@ -40,6 +42,8 @@ struct Limbs {
 template <class C>
 struct Field {
   static constexpr int N = C::NL;
+  static constexpr int RS = C::RS;  // Montgomery radix R = 2^(29 RS)
+  using Consts = C;
   using El = Limbs<N>;
 
   static MSM_HD El zero() {
@@ -139,15 +143,35 @@ struct Field {
   }
   static MSM_HD El cneg(const El& a, bool c) { return select(c, neg(a), a); }
 
-  // Montgomery product a*b*R^-1 mod p, R = 2^(29*N).  Operands canonical (< p).
-  static MSM_HD El mul(const El& a, const El& b) {
+  // ---- Montgomery products, R = 2^(29 RS) ----
+  //
+  // RS = N (Fq): the classic form, a product of canonical operands is < 2p.
+  // RS = N + 1 (Fp: p fills all but half a bit of its 13 limbs, so R = 2^377 leaves no slack at
+  // all): one more reduction step than the operands have limbs.  The operands may then be ANY
+  // 13-limb values below 2^380 -- not reduced mod p -- and the product is below p + 2^354: the
+  // "lazy" forms below (mul_lz, sqr_lz, mul_add_mul_lz) skip the conditional subtraction and the
+  // point formulas replace modular add/sub by limb-wise ones against a multiple of p
+  // (add_kp_sub).  Per mixed addition: 4400 instead of 5350 VALU instructions, 160 instead of
+  // 248 VGPRs (hipcc 7.2, gfx950).
+  //
+  // Column bound (every column of the schoolbook product is ONE u64 accumulator): with limb
+  // bounds A_i, B_j the worst column holds sum A_i B_j + 12 * 2^58 (the q p terms) + a carry
+  // < 2^36.  Allowed operand shapes, checked per call site in g1_xyzz.hpp:
+  //   "N-form"  limbs 0..11 < 2^29, top limb < 2^31.6   (norm() output, value < 7.1 p)
+  //   "lazy"    limbs < 3 * 2^29, top limb < 2^31       (one add_kp_sub of N-form values with top limbs < 2^29.1)
+  // N x N, lazy x N (top limb of the N operand < 2^29.1) and N^2 fit; lazy x lazy does not.
+
+  // Lazy product: see above.  Output N-form with value < p + 2^354 (top limb <= MOD[N-1] + 64).
+  static MSM_HD El mul_lz(const El& a, const El& b) {
     uint64_t t[N];
 #pragma unroll
     for (int j = 0; j < N; j++) t[j] = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < RS; i++) {
+      if (i < N) {
 #pragma unroll
-      for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
+        for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
+      }
       uint32_t q = (0u - (uint32_t)t[0]) & LMASK;
       uint64_t carry = (t[0] + q) >> LB;  // low 29 bits cancel exactly
 #pragma unroll
@@ -164,24 +188,23 @@ struct Field {
       t[j + 1] += t[j] >> LB;
     }
     r.l[N - 1] = (uint32_t)t[N - 1];
-    return reduce_once(r);
+    return r;
   }
 
-  // a*b - c*d in ONE Montgomery reduction: a*b + (p - c)*d accumulates 26 product terms and 12
-  // q*p terms per column (38 * 2^58 < 2^64), the quotient digits serve both products, and the
-  // result (< 2.7 p) takes two conditional subtractions.  Saves the 156 multiply-adds of a second
-  // reduction; used for Y3 = R (Q - X3) - Y1 PPP in every point addition.
-  static MSM_HD El mul_sub_mul(const El& a, const El& b, const El& c, const El& d) {
-    const El e = neg(c);
+  // a*b + e*d in ONE reduction (Y3 = R (Q - X3) + (-Y1) PPP of every point addition): the quotient
+  // digits serve both products.  Same output contract as mul_lz; the column bound covers both sums.
+  static MSM_HD El mul_add_mul_lz(const El& a, const El& b, const El& e, const El& d) {
     uint64_t t[N];
 #pragma unroll
     for (int j = 0; j < N; j++) t[j] = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < RS; i++) {
+      if (i < N) {
 #pragma unroll
-      for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
+        for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
 #pragma unroll
-      for (int j = 0; j < N; j++) t[j] += (uint64_t)e.l[i] * d.l[j];
+        for (int j = 0; j < N; j++) t[j] += (uint64_t)e.l[i] * d.l[j];
+      }
       uint32_t q = (0u - (uint32_t)t[0]) & LMASK;
       uint64_t carry = (t[0] + q) >> LB;
 #pragma unroll
@@ -198,23 +221,24 @@ struct Field {
       t[j + 1] += t[j] >> LB;
     }
     r.l[N - 1] = (uint32_t)t[N - 1];
-    return reduce_once(reduce_once(r));
+    return r;
   }
 
-  // Montgomery square: off-diagonal terms once with a doubled operand (2a_i < 2^30).
-  static MSM_HD El sqr(const El& a) {
-    uint64_t t[2 * N];
+  // Lazy square of an N-form value: off-diagonal terms once with a doubled operand (2 a_i < 2^30 for
+  // i <= N-2; the top limb is never the doubled one).
+  static MSM_HD El sqr_lz(const El& a) {
+    uint64_t t[RS + N];
 #pragma unroll
-    for (int j = 0; j < 2 * N; j++) t[j] = 0;
+    for (int j = 0; j < RS + N; j++) t[j] = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       t[2 * i] += (uint64_t)a.l[i] * a.l[i];
-      uint32_t a2 = a.l[i] << 1;
+      const uint32_t a2 = a.l[i] << 1;
 #pragma unroll
       for (int j = i + 1; j < N; j++) t[i + j] += (uint64_t)a2 * a.l[j];
     }
 #pragma unroll
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < RS; i++) {
       uint32_t q = (0u - (uint32_t)t[i]) & LMASK;
       uint64_t carry = (t[i] + q) >> LB;
 #pragma unroll
@@ -224,12 +248,76 @@ struct Field {
     El r;
 #pragma unroll
     for (int j = 0; j < N - 1; j++) {
-      r.l[j] = (uint32_t)t[N + j] & LMASK;
-      t[N + j + 1] += t[N + j] >> LB;
+      r.l[j] = (uint32_t)t[RS + j] & LMASK;
+      t[RS + j + 1] += t[RS + j] >> LB;
     }
-    r.l[N - 1] = (uint32_t)t[2 * N - 1];
-    return reduce_once(r);
+    r.l[N - 1] = (uint32_t)t[RS + N - 1];
+    return r;
   }
+
+  // Canonical forms: operands canonical (or anything the lazy forms accept), result in [0, p).
+  static MSM_HD El mul(const El& a, const El& b) { return reduce_once(mul_lz(a, b)); }
+  static MSM_HD El sqr(const El& a) { return reduce_once(sqr_lz(a)); }
+  // a*b - c*d with a single Montgomery reduction.  RS = N: a*b + (p - c)*d is < 2.7 p after the
+  // reduction (two conditional subtractions); RS = N + 1: < p + 2^354 (one).
+  static MSM_HD El mul_sub_mul(const El& a, const El& b, const El& c, const El& d) {
+    const El r = mul_add_mul_lz(a, b, neg(c), d);
+    return RS > N ? reduce_once(r) : reduce_once(reduce_once(r));
+  }
+
+  // ---- limb-wise helpers of the lazy formulas (RS = N + 1 only) ----
+
+  // a + K - b - s * b2 limb by limb, no carries: K is a multiple of p from consts_gen.hpp whose limbs
+  // are raised by w * 2^29 (KP2, KP6: w = 1; KP4W3: w = 3), so no limb goes negative as long as
+  // b (+ s b2) has at most w units of 2^29 per limb and a top limb below K's.  The value is
+  // a - b - s b2 + K, congruent to a - b - s b2.
+  static MSM_HD El add_kp_sub(const El& a, const uint32_t (&K)[N], const El& b) {
+    El r;
+#pragma unroll
+    for (int j = 0; j < N; j++) r.l[j] = a.l[j] + K[j] - b.l[j];
+    return r;
+  }
+  static MSM_HD El kp_sub(const uint32_t (&K)[N], const El& b) {  // K - b
+    El r;
+#pragma unroll
+    for (int j = 0; j < N; j++) r.l[j] = K[j] - b.l[j];
+    return r;
+  }
+  static MSM_HD El add_kp_sub_sub2(const El& a, const uint32_t (&K)[N], const El& b, const El& b2) {  // a + K - b - 2 b2
+    El r;
+#pragma unroll
+    for (int j = 0; j < N; j++) r.l[j] = a.l[j] + K[j] - b.l[j] - 2u * b2.l[j];
+    return r;
+  }
+  // Carry propagation only: limbs 0..N-2 back below 2^29, the value (not reduced mod p) unchanged.
+  static MSM_HD El norm(const El& a) {
+    El r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; j++) {
+      const uint32_t v = a.l[j] + c;
+      r.l[j] = v & LMASK;
+      c = v >> LB;
+    }
+    r.l[N - 1] = a.l[N - 1] + c;
+    return r;
+  }
+  // x (N-form) >= m ? x - m : x, for m = MOD, MOD2, MOD4 (top limb of either up to 32 bits).
+  static MSM_HD El csub(const El& x, const uint32_t (&m)[N]) {
+    El d;
+    int32_t bw = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; j++) {
+      const int32_t v = (int32_t)x.l[j] - (int32_t)m[j] + bw;
+      d.l[j] = (uint32_t)v & LMASK;
+      bw = v >> 31;
+    }
+    const int64_t top = (int64_t)x.l[N - 1] - (int64_t)m[N - 1] + bw;
+    d.l[N - 1] = (uint32_t)top;
+    return select(top < 0, x, d);
+  }
+  // Any N-form value below 8 p -> [0, p).  Rare paths only (special cases of the point formulas, output).
+  static MSM_HD El canon(const El& x) { return csub(csub(csub(x, C::MOD4), C::MOD2), C::MOD); }
 
   static MSM_HD El to_mont(const El& a) { return mul(a, from_const(C::R2)); }
   static MSM_HD El from_mont(const El& a) {
@@ -266,7 +354,7 @@ struct Field {
   }
 };
 
-using Fp = Field<G1Consts>;  // BLS12-377 base field, 13 limbs, R = 2^377
+using Fp = Field<G1Consts>;  // BLS12-377 base field, 13 limbs, R = 2^406
 using Fq = Field<EdConsts>;  // Edwards-BLS12 base field (= BLS12-377 scalar field), 9 limbs, R = 2^261
 
 // a^e for a public exponent given as little-endian u32 words (host tail only: inversion).

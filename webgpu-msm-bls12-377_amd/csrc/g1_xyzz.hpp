@@ -16,6 +16,16 @@
 
 namespace msm377 {
 
+// Fields whose Montgomery radix leaves room for the lazy (no conditional subtraction) product forms.
+template <class F>
+struct FieldTraits {
+  static constexpr bool lazy = false;
+};
+template <class C>
+struct FieldTraits<Field<C>> {
+  static constexpr bool lazy = C::RS > C::NL;
+};
+
 // F is a field policy: Fp (29-bit limbs, device + host) or Fp64 (64-bit words, host tail).
 template <class F>
 struct G1T {
@@ -54,8 +64,9 @@ struct G1T {
   }
 
   // EFD dbl-2008-s-1 with a = 0: 6M + 3S.  Y = 0 (a 2-torsion point) yields ZZ3 = 0.
-  static MSM_HD XYZZ dbl(const XYZZ& p) {
-    if (is_identity(p)) return p;
+  static MSM_HD XYZZ dbl(const XYZZ& p0) {
+    if (is_identity(p0)) return p0;
+    const XYZZ p = canon_pt(p0);
     El u = F::dbl(p.y);
     El v = F::sqr(u);
     El w = F::mul(u, v);
@@ -86,8 +97,11 @@ struct G1T {
     return r;
   }
 
-  // acc + q, q affine: EFD madd-2008-s (8M + 2S) plus the cases it does not cover.
-  static MSM_HD XYZZ madd(const XYZZ& a, const Affine& q) {
+  // acc + q (or acc - q), q affine: EFD madd-2008-s (8M + 2S) plus the cases it does not cover.
+  static MSM_HD XYZZ madd(const XYZZ& a, const Affine& q0, bool negq = false) {
+    if constexpr (FieldTraits<F>::lazy) return madd_lz(a, q0, negq);
+    Affine q = q0;
+    if (negq) q.y = F::neg(q0.y);
     if (is_identity(a)) return from_affine(q);
     El u2 = F::mul(q.x, a.zz);
     El s2 = F::mul(q.y, a.zzz);
@@ -110,6 +124,7 @@ struct G1T {
 
   // General addition: EFD add-2008-s (12M + 2S) plus identity / equal / opposite inputs.
   static MSM_HD XYZZ add(const XYZZ& a, const XYZZ& b) {
+    if constexpr (FieldTraits<F>::lazy) return add_lz(a, b);
     if (is_identity(a)) return b;
     if (is_identity(b)) return a;
     El u1 = F::mul(a.x, b.zz);
@@ -132,6 +147,89 @@ struct G1T {
     o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
     return o;
   }
+
+  // ---- lazy forms (F = Fp, field29.hpp "Montgomery products"): no modular reduction inside ----
+  //
+  // Invariant of every stored point:  X is N-form with value < 5p + 2^354;  Y, ZZ, ZZZ are N-form
+  // with value < p + 2^354 (canonical coordinates satisfy both; the identity has ZZ = 0 limb by limb).
+  // Bounds behind each line, with e = 2^354 and "M1" = a lazy product (< p + e):
+  //   P = U2 + 6p - X1  in (p - e, 7p + e)      R = S2 + 2p - Y1  in (p - e, 3p + e)
+  //   X3 = R^2 + 4p - PPP - 2Q  < 5p + e        D = Q + 6p - X3   in (p - e, 7p + e)
+  //   Y3 = (R D + (2p - Y1) PPP) / 2^406 + < p  is M1: R D < 21 p^2, (2p - Y1) PPP < 2 p^2, p / 2^406 < 2^-29
+  // Column sums (limit 2^64): worst is Y3 with R, D N-form (top limbs < 2^30.4, 2^31.6), 2p - Y1 lazy
+  // (limbs < 2^30), PPP M1:  2^61.5 + 2^62.7 + 2^61.6 (q p) < 2^63.5.
+  // P = 0 mod p (equal or opposite points) means P in {p, .., 7p}, whose low limb is 1..7
+  // (p = 1 mod 2^29): one compare guards the exact test.
+  static MSM_HD XYZZ canon_pt(const XYZZ& p) {
+    if constexpr (FieldTraits<F>::lazy) {
+      XYZZ r;
+      r.x = F::canon(p.x);
+      r.y = F::canon(p.y);
+      r.zz = F::canon(p.zz);
+      r.zzz = F::canon(p.zzz);
+      return r;
+    } else {
+      return p;
+    }
+  }
+  static MSM_HD XYZZ madd_lz(const XYZZ& a, const Affine& q, bool negq) {
+    using K = typename F::Consts;
+    if (is_identity(a)) {
+      XYZZ r = from_affine(q);
+      if (negq) r.y = F::neg(q.y);
+      return r;
+    }
+    const El u2 = F::mul_lz(q.x, a.zz);
+    const El s2 = F::mul_lz(F::select(negq, F::kp_sub(K::KP2, q.y), q.y), a.zzz);
+    const El p = F::norm(F::add_kp_sub(u2, K::KP6, a.x));
+    const El r = F::norm(F::add_kp_sub(s2, K::KP2, a.y));
+    if ((p.l[0] - 1u) < 7u) {
+      if (F::is_zero(F::canon(p))) {
+        if (!F::is_zero(F::canon(r))) return identity();  // opposite points
+        Affine t = q;
+        if (negq) t.y = F::neg(q.y);
+        return dbl_affine(t);  // same point
+      }
+    }
+    const El pp = F::sqr_lz(p);
+    const El ppp = F::mul_lz(p, pp);
+    const El qq = F::mul_lz(a.x, pp);
+    XYZZ o;
+    o.x = F::norm(F::add_kp_sub_sub2(F::sqr_lz(r), K::KP4W3, ppp, qq));
+    const El d = F::norm(F::add_kp_sub(qq, K::KP6, o.x));
+    o.y = F::mul_add_mul_lz(r, d, F::kp_sub(K::KP2, a.y), ppp);
+    o.zz = F::mul_lz(a.zz, pp);
+    o.zzz = F::mul_lz(a.zzz, ppp);
+    return o;
+  }
+  // Same bounds with U1, S1 (both M1) in place of X1, Y1: P, R in (p - e, 3p + e).
+  static MSM_HD XYZZ add_lz(const XYZZ& a, const XYZZ& b) {
+    using K = typename F::Consts;
+    if (is_identity(a)) return b;
+    if (is_identity(b)) return a;
+    const El u1 = F::mul_lz(a.x, b.zz);
+    const El u2 = F::mul_lz(b.x, a.zz);
+    const El s1 = F::mul_lz(a.y, b.zzz);
+    const El s2 = F::mul_lz(b.y, a.zzz);
+    const El p = F::norm(F::add_kp_sub(u2, K::KP2, u1));
+    const El r = F::norm(F::add_kp_sub(s2, K::KP2, s1));
+    if ((p.l[0] - 1u) < 3u) {
+      if (F::is_zero(F::canon(p))) {
+        if (!F::is_zero(F::canon(r))) return identity();
+        return dbl(a);
+      }
+    }
+    const El pp = F::sqr_lz(p);
+    const El ppp = F::mul_lz(p, pp);
+    const El qq = F::mul_lz(u1, pp);
+    XYZZ o;
+    o.x = F::norm(F::add_kp_sub_sub2(F::sqr_lz(r), K::KP4W3, ppp, qq));
+    const El d = F::norm(F::add_kp_sub(qq, K::KP6, o.x));
+    o.y = F::mul_add_mul_lz(r, d, F::kp_sub(K::KP2, s1), ppp);
+    o.zz = F::mul_lz(F::mul_lz(a.zz, b.zz), pp);
+    o.zzz = F::mul_lz(F::mul_lz(a.zzz, b.zzz), ppp);
+    return o;
+  }
 };
 
 using G1 = G1T<Fp>;
@@ -141,7 +239,7 @@ MSM_HD G1XYZZ g1_identity() { return G1::identity(); }
 MSM_HD bool g1_is_identity(const G1XYZZ& p) { return G1::is_identity(p); }
 MSM_HD G1XYZZ g1_from_affine(const G1Affine& p) { return G1::from_affine(p); }
 MSM_HD G1XYZZ g1_dbl(const G1XYZZ& p) { return G1::dbl(p); }
-MSM_HD G1XYZZ g1_madd(const G1XYZZ& a, const G1Affine& q) { return G1::madd(a, q); }
+MSM_HD G1XYZZ g1_madd(const G1XYZZ& a, const G1Affine& q, bool negq = false) { return G1::madd(a, q, negq); }
 MSM_HD G1XYZZ g1_add(const G1XYZZ& a, const G1XYZZ& b) { return G1::add(a, b); }
 
 }  // namespace msm377

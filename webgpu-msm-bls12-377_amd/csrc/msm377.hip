@@ -99,13 +99,8 @@ struct G1Dev {
     }
     return p;
   }
-  static __device__ __forceinline__ Base cneg(const Base& p, bool c) {
-    Base r = p;
-    r.y = Fp::cneg(p.y, c);
-    return r;
-  }
   static __device__ __forceinline__ Pt identity() { return G1::identity(); }
-  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q) { return G1::madd(a, q); }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return G1::madd(a, q, negq); }  // a + q or a - q
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return G1::add(a, b); }
   static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
 #pragma unroll
@@ -164,9 +159,9 @@ struct EdDev {
     }
     return p;
   }
-  static __device__ __forceinline__ Base cneg(const Base& p, bool c) { return Ed::cneg(p, c); }
+
   static __device__ __forceinline__ Pt identity() { return Ed::identity(); }
-  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q) { return Ed::madd(a, q); }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Ed::madd(a, Ed::cneg(q, negq)); }
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return Ed::add(a, b); }
   static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
 #pragma unroll
@@ -728,7 +723,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
         nxt = CV::load_base(bases, e_nxt & 0x7fffffffu);
         if (k + 1 < end) e_nn = vi[k + 1];
       }
-      acc = CV::madd(acc, CV::cneg(cur, (e_cur >> 31) != 0));
+      acc = CV::madd(acc, cur, (e_cur >> 31) != 0);
       if (!more) break;
       cur = nxt;
       e_cur = e_nxt;
@@ -864,18 +859,21 @@ __device__ __forceinline__ Fp::El sel4(uint32_t q, const Fp::El& a0, const Fp::E
 // a + b computed by the four lanes of a quad (q = lane & 3); every lane passes the same a, b
 // and every lane receives the full sum.
 __device__ __forceinline__ G1XYZZ g1_add_quad(const G1XYZZ& a, const G1XYZZ& b, uint32_t q) {
-  const Fp::El m1 = Fp::mul(sel4(q, a.x, b.x, a.y, b.y), sel4(q, b.zz, a.zz, b.zzz, a.zzz));
+  using K = G1Consts;  // lazy field forms and their bounds: g1_xyzz.hpp add_lz
+  const Fp::El m1 = Fp::mul_lz(sel4(q, a.x, b.x, a.y, b.y), sel4(q, b.zz, a.zz, b.zzz, a.zzz));
   const Fp::El u1 = quad_bcast<0>(m1), u2 = quad_bcast<1>(m1), s1 = quad_bcast<2>(m1), s2 = quad_bcast<3>(m1);
-  const Fp::El p = Fp::sub(u2, u1), rr0 = Fp::sub(s2, s1);
-  if (G1::is_identity(a) || G1::is_identity(b) || Fp::is_zero(p)) return G1::add(a, b);  // uniform inside the quad
-  const Fp::El m2 = Fp::mul(sel4(q, p, rr0, a.zz, a.zzz), sel4(q, p, rr0, b.zz, b.zzz));
+  const Fp::El p = Fp::norm(Fp::add_kp_sub(u2, K::KP2, u1)), rr0 = Fp::norm(Fp::add_kp_sub(s2, K::KP2, s1));
+  if (G1::is_identity(a) || G1::is_identity(b) || ((p.l[0] - 1u) < 3u && Fp::is_zero(Fp::canon(p)))) return G1::add(a, b);  // uniform inside the quad
+  const Fp::El m2 = Fp::mul_lz(sel4(q, p, rr0, a.zz, a.zzz), sel4(q, p, rr0, b.zz, b.zzz));
   const Fp::El pp = quad_bcast<0>(m2), rsq = quad_bcast<1>(m2);
-  const Fp::El m3 = Fp::mul(sel4(q, p, u1, m2, p), pp);  // lane 3 idles on a copy of lane 0's product
+  const Fp::El m3 = Fp::mul_lz(sel4(q, p, u1, m2, p), pp);  // lane 3 idles on a copy of lane 0's product
   const Fp::El ppp = quad_bcast<0>(m3), qq = quad_bcast<1>(m3);
   G1XYZZ o;
-  o.x = Fp::sub(Fp::sub(rsq, ppp), Fp::dbl(qq));
-  const Fp::El m4 = Fp::mul(sel4(q, rr0, s1, rr0, m2), sel4(q, Fp::sub(qq, o.x), ppp, ppp, ppp));
-  o.y = Fp::sub(quad_bcast<0>(m4), quad_bcast<1>(m4));
+  o.x = Fp::norm(Fp::add_kp_sub_sub2(rsq, K::KP4W3, ppp, qq));
+  const Fp::El m4 = Fp::mul_lz(sel4(q, rr0, s1, rr0, m2), sel4(q, Fp::norm(Fp::add_kp_sub(qq, K::KP6, o.x)), ppp, ppp, ppp));
+  // Y3 = lane 0 - lane 1 is a difference of two reduced products here (no fused form across lanes): bring it
+  // back below p so that the stored Y keeps the < p + 2^354 invariant.
+  o.y = Fp::canon(Fp::norm(Fp::add_kp_sub(quad_bcast<0>(m4), K::KP2, quad_bcast<1>(m4))));
   o.zz = quad_bcast<2>(m3);
   o.zzz = quad_bcast<3>(m4);
   return o;
