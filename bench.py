@@ -207,7 +207,10 @@ def main():
     # bucket reduction, host tail -- that dominate once the additions are spread out); scalars outside the GLV range
     # make every rank fall back to the plain 16 windows (all ranks see the same scalars, so they agree).
     use_glv = 1 < world <= 8 and os.environ.get("MSM377_BENCH_GLV", "1") == "1"
-    glv_single = world == 1 and os.environ.get("MSM377_GLV", "2") != "0"  # the engine's default front end (include/msm377.h)
+    # the engine's defaults (include/msm377.h): twisted Edwards form, 16 plain windows; MSM377_G1_FORM=0 MSM377_GLV=1
+    # selects the Weierstrass XYZZ path behind the GLV front end
+    te_single = world == 1 and os.environ.get("MSM377_G1_FORM", "1") != "0"
+    glv_single = world == 1 and not te_single and os.environ.get("MSM377_GLV", "0") == "1"
     sharder = ShardedMsm(rank, world, device=xdev)
     sharder_glv = ShardedMsm(rank, world, device=xdev, num_windows=8) if use_glv else None
 
@@ -273,6 +276,7 @@ def main():
             "config": {
                 "workload": "2^%d BLS12-377 G1 (short Weierstrass) MSM, 16-bit signed windows, inputs resident in HBM" % args.log_n,
                 "front_end": "GLV: 8 windows over the 2n points {P_i, phi(P_i)}" if glv_path else "plain: 16 windows over n points",
+                "coordinates": "twisted Edwards form of G1, extended coordinates (csrc/te377.hpp)" if te_single else "short Weierstrass, XYZZ",
                 "points": "P_i=[a_i]G, a_i=SplitMix64(0x377)",
                 "scalars": "uniform < r, SplitMix64(0x5ca1a5)",
                 "parallelism": ("%s windows sharded over %d GPUs, one RCCL all-gather" % ("8 GLV" if use_glv else "16", world)) if world > 1 else "single GPU",

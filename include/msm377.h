@@ -136,13 +136,21 @@ int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint3
 /* Convert one Montgomery XYZZ point (52 words) to the affine wire format (host-only). */
 int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
 
-/* GLV front end for the G1 full-MSM entry points (msm, msm_device, set_bases + fixed_base*):
- * k = k1 + k2 LAMBDA, 8 windows over the 2n points {P_i, phi(P_i)}.
- * Results are identical; scalars outside the GLV range (>~ 2^254) rerun on the plain 16-window path
- * automatically.  mode 0 = never (the plain path), 1 = always, 2 = auto (default; currently GLV at
- * every size: 1.24 vs 1.39 ms at 2^18, 3.51 vs 3.56 ms at 2^20, 12.4 vs 12.6 ms at 2^22).  Stage
- * read-backs need the plain path (mode 0). */
+/* GLV front end of the Weierstrass form (msm377_ctx_set_g1_form 0) of the G1 full-MSM entry points:
+ * k = k1 + k2 LAMBDA, 8 windows over the 2n points {P_i, phi(P_i)}.  OPT-IN:
+ * phi(P) = [LAMBDA] P holds only in the prime-order subgroup, so mode 1 is a promise by the caller that every
+ * input point lies in it (true for every protocol use; the reference makes no such assumption, hence the
+ * default 0; 2 = the library's choice = 0).  Scalars outside the GLV range (>~ 2^254) rerun on the plain
+ * 16-window path automatically.  1.24 vs 1.39 ms at 2^18, 3.51 vs 3.56 ms at 2^20, 12.4 vs 12.6 ms at 2^22. */
 int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
+
+/* Internal coordinate system of the G1 full-MSM entry points (msm, msm_device, set_bases + fixed_base*); results
+ * are identical.  form 1 (default): the twisted Edwards form of BLS12-377 G1 (csrc/te377.hpp) -- 8 field products
+ * per bucket addition instead of 10, no case distinctions; inputs that hit an exceptional case of its addition law
+ * (only possible with points outside the prime-order subgroup) rerun in form 0 automatically.  form 0: short
+ * Weierstrass XYZZ coordinates behind the GLV front end selected by msm377_ctx_set_glv; the stage read-backs and
+ * the window-partials entry points always use it. */
+int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 

@@ -5,6 +5,7 @@
 
 #include "fp64_host.hpp"
 #include "g1_xyzz.hpp"
+#include "te377.hpp"
 
 using namespace msm377;
 
@@ -72,6 +73,52 @@ void shim_g1_add_chain(const uint32_t* pts52, uint32_t count, uint32_t* out52) {
   G1XYZZ acc = load_xyzz(pts52);
   for (uint32_t k = 1; k < count; k++) acc = g1_add(load_xyzz(pts52 + 52 * k), acc);
   store_xyzz(acc, out52);
+}
+// ---- twisted Edwards form of G1 (csrc/te377.hpp) ----
+static TeH::Ext te_to_host(const Te377::Ext& p) {
+  TeH::Ext h;
+  h.x = Fp64::from_limbs29_mont(p.x.l);
+  h.y = Fp64::from_limbs29_mont(p.y.l);
+  h.t = Fp64::from_limbs29_mont(p.t.l);
+  h.z = Fp64::from_limbs29_mont(p.z.l);
+  return h;
+}
+// sum of (+-) wire points through from_wire + madd (k_accumulate's loop), optionally split into `parts` partial sums
+// that are merged with the general addition; result in the Weierstrass wire format.  Returns 1 if any step was flagged
+// exceptional (is_bad / unrepresentable input).
+int shim_te_sum(const uint32_t* q24s, const uint8_t* negs, uint32_t count, uint32_t parts, int phi, uint8_t* out96, uint32_t* ext52) {
+  int bad = 0;
+  Te377::Ext total = Te377::identity();
+  for (uint32_t part = 0; part < parts; part++) {
+    Te377::Ext acc = Te377::identity();
+    for (uint32_t k = part; k < count; k += parts) {
+      const Te377::PBase b = Te377::from_wire(q24s + 24 * k, q24s + 24 * k + 12, phi != 0);
+      bad |= Fp::is_zero(b.z2);
+      acc = Te377::madd(acc, b, negs[k] != 0);
+      bad |= Te377::is_bad(acc);
+    }
+    total = Te377::add(total, acc);
+    bad |= Te377::is_bad(total);
+  }
+  for (int j = 0; j < 13; j++) {
+    ext52[j] = total.x.l[j];
+    ext52[13 + j] = total.y.l[j];
+    ext52[26 + j] = total.t.l[j];
+    ext52[39 + j] = total.z.l[j];
+  }
+  teh_to_wire(te_to_host(total), out96);
+  return bad;
+}
+// [k] P on the host tail's field (TeH doubling and addition), P given in wire format
+void shim_teh_scalar_mul(const uint32_t* q24, const uint32_t* k8, uint8_t* out96) {
+  const Te377::PBase b = Te377::from_wire(q24, q24 + 12, false);
+  const TeH::Ext p = te_to_host(Te377::madd(Te377::identity(), b, false));
+  TeH::Ext acc = TeH::identity();
+  for (int i = 255; i >= 0; i--) {
+    acc = TeH::dbl(acc);
+    if ((k8[i >> 5] >> (i & 31)) & 1u) acc = TeH::add(acc, p);
+  }
+  teh_to_wire(acc, out96);
 }
 void shim_g1_add(const uint32_t* a52, const uint32_t* b52, uint32_t* out52) { store_xyzz(g1_add(load_xyzz(a52), load_xyzz(b52)), out52); }
 void shim_g1_dbl(const uint32_t* a52, uint32_t* out52) { store_xyzz(g1_dbl(load_xyzz(a52)), out52); }

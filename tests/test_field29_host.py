@@ -149,6 +149,61 @@ def test_lazy_accumulation_chains(shim):
     assert util.affine_from_xyzz_words(list(out)) == expected_total
 
 
+def test_twisted_edwards_form_of_g1(shim):
+    """csrc/te377.hpp on the host: wire point -> projective Edwards record -> mixed additions with signs (repeated
+    and opposite points included: the unified law has no special cases) -> general additions -> back to the
+    Weierstrass wire format; and the host tail's doubling / addition through a scalar multiplication."""
+    rnd = random.Random(77)
+    pts = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(9)]
+    beta_pts = None
+    for trial in range(14):
+        count = rnd.choice([1, 2, 3, 7, 30])
+        parts = rnd.choice([1, 2, 3])
+        seq = [rnd.choice(pts) for _ in range(count)]
+        negs = [rnd.randrange(2) for _ in range(count)]
+        if trial == 0:
+            seq, negs, count, parts = [pts[0]] * 5, [0, 0, 1, 0, 1], 5, 1  # P + P - P + P - P
+        if trial == 1:
+            seq, negs, count, parts = [pts[2], pts[2]], [0, 1], 2, 1  # sums to the identity
+        phi = trial % 5 == 4
+        q = (ctypes.c_uint32 * (24 * count))(*[w for pt in seq for w in xy24(pt)])
+        out = ctypes.create_string_buffer(96)
+        ext = (ctypes.c_uint32 * 52)()
+        bad = shim.shim_te_sum(q, (ctypes.c_uint8 * count)(*negs), count, parts, int(phi), out, ext)
+        assert bad == 0
+        exp = None
+        for pt, ng in zip(seq, negs):
+            if phi:
+                pt = R.mul(pt, 0x8508C00000000001 ** 2 - 1)  # phi(P) = [LAMBDA] P
+            exp = R.add(exp, R.neg(pt) if ng else pt)
+        assert out.raw == R.encode_result(exp), trial
+        words = list(ext)
+        for c in range(4):  # stored coordinates: lazy products, carry-normalised, below p + 2^354
+            assert all(w < (1 << 29) for w in words[13 * c : 13 * c + 13])
+            assert sum(int(w) << (29 * i) for i, w in enumerate(words[13 * c : 13 * c + 13])) < R.P + (1 << 354)
+    for k in [0, 1, 2, R.R_ORDER - 1, rnd.randrange(R.R_ORDER), (1 << 253) - 1]:
+        out = ctypes.create_string_buffer(96)
+        shim.shim_teh_scalar_mul(xy24(pts[3]), (ctypes.c_uint32 * 8)(*[(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)]), out)
+        assert out.raw == R.encode_result(R.mul(pts[3], k)), k
+
+
+def test_twisted_edwards_exceptional_inputs_are_flagged(shim):
+    """The two curve points the map does not cover -- (-1, 0) of order 2 and the order-4 points over it -- and
+    sums that land on a point at infinity of the Edwards model must raise the flag (the engine then reruns on the
+    Weierstrass path); they can only come from outside the prime-order subgroup."""
+    two_torsion = (R.P - 1, 0)
+    assert R.add(two_torsion, two_torsion) is None
+    out = ctypes.create_string_buffer(96)
+    ext = (ctypes.c_uint32 * 52)()
+    assert shim.shim_te_sum(xy24(two_torsion), (ctypes.c_uint8 * 1)(0), 1, 1, 0, out, ext) == 1
+    # Q = P + T2 for a subgroup point P: P - Q = T2 is exceptional for the Edwards law
+    p = R.mul(R.G, 12345)
+    qpt = R.add(p, two_torsion)
+    q = (ctypes.c_uint32 * 48)(*(list(xy24(p)) + list(xy24(qpt))))
+    bad = shim.shim_te_sum(q, (ctypes.c_uint8 * 2)(0, 1), 2, 1, 0, out, ext)
+    assert bad == 1 or out.raw == R.encode_result(two_torsion)
+
+
 def test_lazy_bounds_proof():
     """tools/check_lazy_bounds.py: interval replay of the lazy formulas -- no 64-bit column can overflow, no limb
     of a limb-wise subtraction can go negative, results meet the storage invariant."""

@@ -67,10 +67,12 @@ def test_g1_fuzz(engine, oracle, seed):
     pb, sb = R.encode_points(pts), R.encode_scalars(ks)
     exp = util.oracle_msm(oracle, pb, sb)
     try:
-        for mode in (False, True, "auto"):  # plain 16-window path, GLV front end, the default choice
-            engine.set_glv(mode)
-            assert engine.msm(pb, sb) == exp, mode
+        for form, glv in (("edwards", "auto"), ("weierstrass", True), ("weierstrass", False)):
+            engine.set_g1_form(form)  # twisted Edwards form (default); Weierstrass XYZZ behind GLV; plain 16 windows
+            engine.set_glv(glv)
+            assert engine.msm(pb, sb) == exp, (form, glv)
     finally:
+        engine.set_g1_form("edwards")
         engine.set_glv("auto")
 
 

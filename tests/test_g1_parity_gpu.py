@@ -75,7 +75,8 @@ def test_stage_parity(engine, oracle):
     n = 5000
     pts, ks = seeded_inputs(oracle, n, 4242)
     engine.set_stage_capture(True)
-    engine.set_glv(False)  # the stage read-backs describe the plain 16-window path
+    engine.set_g1_form("weierstrass")  # the stage read-backs describe the plain 16-window XYZZ path
+    engine.set_glv(False)
     try:
         res = engine.msm(pts, ks)
         assert res == util.oracle_msm(oracle, pts, ks)
@@ -117,13 +118,26 @@ def test_stage_parity(engine, oracle):
     finally:
         engine.set_stage_capture(False)
         engine.set_glv("auto")
+        engine.set_g1_form("edwards")
 
 
-@pytest.mark.parametrize("glv", [True, False])
-def test_glv_and_plain_front_ends(engine, oracle, golden, glv):
-    """f4: the GLV front end (k = k1 + k2 LAMBDA, 8 windows over {P_i, phi(P_i)}) and the plain 16-window path
-    give the oracle's result on the same inputs."""
-    engine.set_glv(glv)
+def select_path(engine, path):
+    """The three internal paths of the G1 entry points: twisted Edwards form (default), Weierstrass XYZZ behind the
+    GLV front end, Weierstrass XYZZ with the plain 16 windows."""
+    engine.set_g1_form("edwards" if path == "edwards" else "weierstrass")
+    engine.set_glv({"edwards": "auto", "glv": True, "plain": False}[path])
+
+
+def default_path(engine):
+    engine.set_g1_form("edwards")
+    engine.set_glv("auto")
+
+
+@pytest.mark.parametrize("path", ["edwards", "glv", "plain"])
+def test_glv_and_plain_front_ends(engine, oracle, golden, path):
+    """f4: the twisted Edwards form, the GLV front end (k = k1 + k2 LAMBDA, 8 windows over {P_i, phi(P_i)}) and the
+    plain 16-window Weierstrass path give the oracle's result on the same inputs."""
+    select_path(engine, path)
     try:
         for name, case in golden.items():
             if name.startswith("g1_"):
@@ -132,7 +146,7 @@ def test_glv_and_plain_front_ends(engine, oracle, golden, glv):
             pts, ks = seeded_inputs(oracle, n, 31 + n)
             assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks), n
     finally:
-        engine.set_glv("auto")
+        default_path(engine)
 
 
 def test_scalars_outside_the_glv_range_fall_back(engine, oracle):
@@ -145,18 +159,21 @@ def test_scalars_outside_the_glv_range_fall_back(engine, oracle):
     ks_int[200] = (1 << 255) - (1 << 240)
     ks2 = R.encode_scalars(ks_int)
     exp = R.encode_result(R.msm_naive(R.decode_points(pts), ks_int))
-    engine.set_glv(True)
+    select_path(engine, "glv")
     try:
         assert engine.msm(pts, ks2) == exp
         engine.set_bases(pts)
         assert engine.msm_fixed_base(ks2) == exp
         assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
     finally:
-        engine.set_glv("auto")
+        default_path(engine)
+    assert engine.msm(pts, ks2) == exp  # Edwards form: 16 plain windows, no range limit below 2^255 - 2^239
 
 
-def test_bucket_boundaries_and_signs(engine, oracle):
+@pytest.mark.parametrize("path", ["edwards", "glv", "plain"])
+def test_bucket_boundaries_and_signs(engine, oracle, path):
     """Digits hitting 0, +-1, +2^15-1, -2^15 in every window; repeated and opposite points."""
+    select_path(engine, path)
     g = R.G
     p2 = R.mul(g, 2)
     pts = [g, g, R.neg(g), p2, R.neg(p2), g, p2, g]
@@ -164,28 +181,75 @@ def test_bucket_boundaries_and_signs(engine, oracle):
     ks = [full(0x8000), full(0x8000), full(0x8000), full(0x7FFF), full(0x7FFF), full(1), full(0xFFFF) % R.R_ORDER, 0]
     pb, sb = R.encode_points(pts), R.encode_scalars(ks)
     exp = R.encode_result(R.msm_naive(pts, ks))
-    assert engine.msm(pb, sb) == exp == util.oracle_msm(oracle, pb, sb, "oracle_g1_msm_naive")
+    try:
+        assert engine.msm(pb, sb) == exp == util.oracle_msm(oracle, pb, sb, "oracle_g1_msm_naive")
+    finally:
+        default_path(engine)
 
 
-def test_one_repeated_base_point(engine, oracle):
+@pytest.mark.parametrize("path", ["edwards", "glv", "plain"])
+def test_one_repeated_base_point(engine, oracle, path):
     """The harness's 'random inputs' mode: ONE base point repeated (src/ui/AllBenchmarks.tsx:84-88),
     so every bucket with two entries doubles."""
+    select_path(engine, path)
     n = 3000
     pts = R.encode_points([R.FIXED_BASE]) * n
     ks = R.encode_scalars(R.rand_scalars(31337, n))
     total = sum(R.decode_scalars(ks)) % R.R_ORDER
     exp = R.encode_result(R.mul(R.FIXED_BASE, total))
-    assert engine.msm(pts, ks) == exp
+    try:
+        assert engine.msm(pts, ks) == exp
+    finally:
+        default_path(engine)
 
 
+@pytest.mark.parametrize("path", ["edwards", "plain"])
 @pytest.mark.parametrize("n", [65, 130, 200, 2048])
-def test_all_same_scalar(engine, oracle, n):
+def test_all_same_scalar(engine, oracle, n, path):
     """Maximally skewed buckets: every point lands in the same bucket of each window, so every row is
     split into work items and merged (2, 3, 4 and 32 segments)."""
     pts, _ = seeded_inputs(oracle, n, 77)
     k = R.rand_scalars(78, 1)[0]
     ks = R.encode_scalars([k] * n)
-    assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+    select_path(engine, path)
+    try:
+        assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+    finally:
+        default_path(engine)
+
+
+def test_points_outside_the_prime_order_subgroup(engine, oracle):
+    """The Edwards form's addition law has exceptional pairs, all involving points of even order (csrc/te377.hpp):
+    the map does not cover the 2-torsion point (-1, 0), and P, Q with P - Q of order 2 hit a point at infinity of the
+    model.  Valid curve points all the same: the engine must notice (conversion / per-addition Z = 0 check) and rerun
+    on the Weierstrass path -- full MSM, resident table, batch."""
+    t2 = (R.P - 1, 0)
+    rnd_pts = R.decode_points(seeded_inputs(oracle, 40, 4040)[0])
+    shifted = [R.add(p, t2) for p in rnd_pts[:10]]
+    for a in shifted:
+        assert (a[1] * a[1] - a[0] ** 3 - 1) % R.P == 0
+    cases = {
+        "two-torsion input": rnd_pts[:5] + [t2] + rnd_pts[5:9],
+        "P and P + T2 in one bucket": [rnd_pts[0], shifted[0]] + rnd_pts[1:4],
+        "cofactor points only": shifted,
+    }
+    for name, pts in cases.items():
+        n = len(pts)
+        ks = R.rand_scalars(len(name), n)
+        if name.startswith("P and"):
+            ks[0], ks[1] = 5, 5  # same digits, same buckets: P + (P + T2)
+        exp = R.encode_result(R.msm_naive(pts, ks))
+        pb, sb = R.encode_points(pts), R.encode_scalars(ks)
+        assert engine.msm(pb, sb) == exp, name
+        engine.set_bases(pb)
+        assert engine.msm_fixed_base(sb) == exp, name
+        assert engine.msm_fixed_base(sb) == exp, name  # the table stays in the form it fell back to
+        d_s = dev(sb + sb)
+        assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 2) == [exp, exp], name
+    # P - (P + T2) = -T2: opposite signs of the same digit
+    pts = [rnd_pts[0], shifted[0]]
+    ks = [7, R.R_ORDER - 7]
+    assert engine.msm(R.encode_points(pts), R.encode_scalars(ks)) == R.encode_result(R.msm_naive(pts, ks))
 
 
 def test_scalar_overflow_is_an_error(engine, golden):
@@ -229,16 +293,16 @@ def test_fixed_base_batches(engine, oracle):
     assert e.value.code == -5
 
 
-@pytest.mark.parametrize("glv", [False, True])
-def test_fixed_base_batch_pipeline(engine, oracle, glv):
+@pytest.mark.parametrize("path", ["edwards", "glv", "plain"])
+def test_fixed_base_batch_pipeline(engine, oracle, path):
     """BASELINE.json config 5 shape: one resident base set, a batch of scalar sets in ONE call (the host
     tail of each MSM overlaps the next MSM's GPU work); every result equals the oracle's."""
     n, batch = 2500, 5
     pts, _ = seeded_inputs(oracle, n, 55)
     sets = [R.encode_scalars(R.rand_scalars(7000 + b, n)) for b in range(batch)]
-    engine.set_glv(glv)
+    select_path(engine, path)
     engine.set_bases(pts)
-    engine.set_glv("auto")  # the resident table remembers how it was built
+    default_path(engine)  # the resident table remembers how it was built
     d_s = dev(b"".join(sets))
     got = engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, batch)
     assert got == [util.oracle_msm(oracle, pts, s) for s in sets]

@@ -124,6 +124,10 @@ def kp_sub(kname, k, b, name):
     return V(list(Kl), k * P - b.lo + 1, max(0, k * P - b.hi), name)
 
 
+def add_lz(a, b, name):
+    return V([x + y for x, y in zip(a.limbs, b.limbs)], a.hi + b.hi, a.lo + b.lo, name)
+
+
 def norm(a, name):
     assert a.hi < (1 << 380), (name, a.hi / P)
     return nform(a.hi, a.lo, name)
@@ -181,6 +185,27 @@ def main():
     b = mul_lz(s1, ppp, "quad S1*PPP")
     y = norm(add_kp_sub(a, "KP2", 2, b, "quad Y3"), "quad Y3")
     canon_ok(y, "quad canon(Y3)")
+
+    # ---- te377.hpp: twisted Edwards form; every stored coordinate is a lazy product (M1), base records canonical ----
+    def te_finish(a, b, c, d, tag):
+        e = norm(add_kp_sub(b, "KP2", 2, a, tag + " E"), tag + " E")
+        f = norm(add_kp_sub(d, "KP2", 2, c, tag + " F"), tag + " F")
+        g = norm(add_lz(d, c, tag + " G"), tag + " G")
+        h = add_lz(b, a, tag + " H")
+        for nm, (x, y) in (("X3", (e, f)), ("Y3", (h, g)), ("T3", (h, e)), ("Z3", (f, g))):
+            mul_lz(x, y, "%s %s" % (tag, nm))
+
+    PX, PY, PT, PZ = m1("PX"), m1("PY"), m1("PT"), m1("PZ")
+    a = mul_lz(add_kp_sub(PY, "KP2", 2, PX, "te madd Y-X"), canonical, "te madd A")
+    b = mul_lz(add_lz(PY, PX, "te madd Y+X"), canonical, "te madd B")
+    c = mul_lz(kp_sub("KP2", 2, canonical, "te madd -kt"), PT, "te madd C")
+    d = mul_lz(PZ, canonical, "te madd D")
+    te_finish(a, b, c, d, "te madd")
+    a = mul_lz(norm(add_kp_sub(PY, "KP2", 2, PX, "te add Y1-X1"), "te add Y1-X1"), norm(add_kp_sub(PY, "KP2", 2, PX, "te add Y2-X2"), "te add Y2-X2"), "te add A")
+    b = mul_lz(norm(add_lz(PY, PX, "te add Y1+X1"), "te add Y1+X1"), norm(add_lz(PY, PX, "te add Y2+X2"), "te add Y2+X2"), "te add B")
+    c = mul_lz(mul_lz(PT, PT, "te add T1T2"), canonical, "te add C")
+    d = mul_lz(PZ, PZ, "te add D")
+    te_finish(a, b, c, add_lz(d, d, "te add 2D"), "te add")
 
     # canonical operations on stored (lazy) coordinates: mul() = reduce_once(mul_lz()) needs mul_lz < 2p
     mul_lz(X1, canonical, "gather X*TO64")

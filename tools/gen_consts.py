@@ -130,6 +130,48 @@ def _find_beta():
     raise AssertionError("no beta matches LAMBDA")
 
 
+# ---- BLS12-377 G1 as a twisted Edwards curve with a = -1 ----
+# W: y^2 = x^3 + 1 has the 2-torsion point (-1, 0).  With s = 1/sqrt(3):  u = s (x + 1), v = s y is the Montgomery
+# curve s v^2 = u^3 - 3 s u^2 + u, and  xe0 = u / v, ye = (u - 1) / (u + 1)  the twisted Edwards curve
+# a0 xe0^2 + ye^2 = 1 + d0 xe0^2 ye^2 with a0 = (A + 2) / B, d0 = (A - 2) / B (A = -3 s, B = s).  -a0 is a square in
+# Fp, so xe = c xe0 with c = sqrt(-a0) gives  -xe^2 + ye^2 = 1 + d xe^2 ye^2,  d = -d0 / a0.  d is a square: the
+# addition law has exceptional pairs, all involving points of even order -- never inside the prime-order subgroup
+# (see csrc/te377.hpp for how the engine detects and survives them).
+def _sqrt_p(a):
+    a %= P
+    assert pow(a, (P - 1) // 2, P) == 1
+    q, e = P - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        e += 1
+    z = 2
+    while pow(z, (P - 1) // 2, P) == 1:
+        z += 1
+    m, c, t, r = e, pow(z, q, P), pow(a, q, P), pow(a, (q + 1) // 2, P)
+    while t != 1:
+        i, tt = 0, t
+        while tt != 1:
+            tt = tt * tt % P
+            i += 1
+        b = pow(c, 1 << (m - i - 1), P)
+        m, c, t, r = i, b * b % P, t * b * b % P, r * b % P
+    return min(r, P - r)
+
+
+def te_params():
+    s = pow(_sqrt_p(3), -1, P)
+    A, B = (-3 * s) % P, s
+    a0 = (A + 2) * pow(B, -1, P) % P
+    d0 = (A - 2) * pow(B, -1, P) % P
+    c = _sqrt_p(-a0)
+    d = (-d0) * pow(a0, -1, P) % P
+    # self-check on the generator: the image satisfies the a = -1 curve equation
+    u, v = s * (GX + 1) % P, s * GY % P
+    xe, ye = c * u * pow(v, -1, P) % P, (u - 1) * pow(u + 1, -1, P) % P
+    assert (-xe * xe + ye * ye - 1 - d * xe * xe * ye * ye) % P == 0
+    return {"s": s, "c": c, "d": d}
+
+
 def emit_glv():
     assert (GLV_LAMBDA * GLV_LAMBDA + GLV_LAMBDA + 1) % Q == 0 and GLV_LAMBDA.bit_length() == 127
     mu = (1 << 384) // GLV_LAMBDA
@@ -153,10 +195,18 @@ def main():
     dst = os.path.join(here, "..", "webgpu-msm-bls12-377_amd", "csrc", "consts_gen.hpp")
     s = "// GENERATED by tools/gen_consts.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\n"
     s += "namespace msm377 {\n\n"
-    s += emit("G1Consts", P, 13, {"GEN_X": GX, "GEN_Y": GY, "B3": 3, "BETA": GLV_BETA}, rs=14, lazy=True)
+    te = te_params()
+    s_, c_, d_ = te["s"], te["c"], te["d"]
+    R29 = 1 << (LB * 14)
+    g1_extra = {"GEN_X": GX, "GEN_Y": GY, "B3": 3, "BETA": GLV_BETA,
+                # twisted Edwards form (csrc/te377.hpp): Montgomery forms of s, c s, 2d; and the raw (non-Montgomery)
+                # multipliers s R, c s R that take a RAW wire coordinate straight to the Montgomery form of s x, c s x
+                "TE_S": s_, "TE_CS": c_ * s_, "TE_2D": 2 * d_, "TE_SR": s_ * R29, "TE_CSR": c_ * s_ * R29,
+                "TE_SBR": s_ * GLV_BETA * R29, "TE_CSBR": c_ * s_ * GLV_BETA * R29}
+    s += emit("G1Consts", P, 13, g1_extra, rs=14, lazy=True)
     s += emit_glv()
     s += emit("EdConsts", Q, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D, "GEN_X": ED_GX, "GEN_Y": ED_GY})
-    s += emit64("G1Consts64", P, 6, 14)
+    s += emit64("G1Consts64", P, 6, 14, {"TE_2D": 2 * d_, "TE_INV_S": pow(s_, -1, P), "TE_C_OVER_S": c_ * pow(s_, -1, P)})
     s += emit64("EdConsts64", Q, 4, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D})
     s += "}  // namespace msm377\n"
     with open(dst, "w") as f:

@@ -277,6 +277,12 @@ struct Field {
     for (int j = 0; j < N; j++) r.l[j] = a.l[j] + K[j] - b.l[j];
     return r;
   }
+  static MSM_HD El add_lz(const El& a, const El& b) {  // a + b, limb-wise
+    El r;
+#pragma unroll
+    for (int j = 0; j < N; j++) r.l[j] = a.l[j] + b.l[j];
+    return r;
+  }
   static MSM_HD El kp_sub(const uint32_t (&K)[N], const El& b) {  // K - b
     El r;
 #pragma unroll

@@ -261,6 +261,55 @@ inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[9
   g1h_to_wire(acc, out);
 }
 
+// ---- G1 tail in twisted Edwards form (csrc/te377.hpp) ----
+struct TeK64 {
+  static Fp64::El two_d() { return Fp64::from_const(G1Consts64::TE_2D); }
+};
+using TeH = EdT<Fp64, TeK64>;
+
+inline TeH::Ext teh_from_record_words(const uint32_t* w48) {  // X, Y, T, Z as 12 u32 words each, host Montgomery form
+  TeH::Ext p;
+  p.x = Fp64::from_words32(w48);
+  p.y = Fp64::from_words32(w48 + 12);
+  p.t = Fp64::from_words32(w48 + 24);
+  p.z = Fp64::from_words32(w48 + 36);
+  return p;
+}
+// Back to the Weierstrass wire format (Z != 0: the GPU side has checked every addition).  With xe = X/Z, ye = Y/Z:
+//   u = (1 + ye) / (1 - ye),  v = c u / xe,  x = u / s - 1,  y = v / s
+//   => x = (Z + Y) X / (s (Z - Y) X) - 1,   y = c (Z + Y) Z / (s (Z - Y) X)        one inversion.
+// X = 0 is the identity (Y = Z; wire x = 0, y = 1 like submission.ts:93-95) or the 2-torsion point (-1, 0) (Y = -Z).
+inline void teh_to_wire(const TeH::Ext& p, uint8_t out[96]) {
+  memset(out, 0, 96);
+  if (Fp64::is_zero(p.x)) {
+    if (Fp64::is_zero(Fp64::sub(p.y, p.z))) {
+      out[48] = 1;
+    } else {
+      Fp64::to_wire(Fp64::neg(Fp64::one()), out);  // x = -1, y = 0
+    }
+    return;
+  }
+  const Fp64::El zy = Fp64::add(p.z, p.y);
+  const Fp64::El inv = Fp64::inv(Fp64::mul(Fp64::sub(p.z, p.y), p.x));
+  const Fp64::El t = Fp64::mul(zy, inv);
+  const Fp64::El x = Fp64::sub(Fp64::mul(Fp64::mul(t, p.x), Fp64::from_const(G1Consts64::TE_INV_S)), Fp64::one());
+  const Fp64::El y = Fp64::mul(Fp64::mul(t, p.z), Fp64::from_const(G1Consts64::TE_C_OVER_S));
+  Fp64::to_wire(x, out);
+  Fp64::to_wire(y, out + 48);
+}
+// Same Horner as g1h_combine over Edwards partial records.
+inline void teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+  TeH::Ext acc = TeH::identity();
+  for (int b = 16 * num_windows - 1; b >= 0; b--) {
+    acc = TeH::dbl(acc);
+    const int w = b >> 4, l = b & 15;
+    const uint32_t* base = partials + (size_t)w * 16 * 48;
+    if (l < 15) acc = TeH::add(acc, teh_from_record_words(base + (size_t)(1 + l) * 48));
+    if (l == 0) acc = TeH::add(acc, teh_from_record_words(base));
+  }
+  teh_to_wire(acc, out);
+}
+
 // ---- Edwards tail ----
 struct EdK64 {
   static Fq64::El two_d() { return Fq64::from_const(EdConsts64::ED_2D); }

@@ -34,6 +34,7 @@
 
 #include "../../include/msm377.h"
 #include "fp64_host.hpp"
+#include "te377.hpp"
 #include "g1_xyzz.hpp"
 
 using namespace msm377;
@@ -43,13 +44,13 @@ namespace {
 constexpr uint32_t NB = 32768;     // buckets per window: |d| = 1..32768
 constexpr uint32_t NBIN = NB + 1;  // sort keys 0..32768 (key 0 = digit 0, never accumulated)
 constexpr uint32_t RP = NBIN + 1;  // row_ptr entries per window
-constexpr uint32_t REC_WORDS = 32; // one base record, 128 bytes
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
 constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) blocks of the partition pass
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
 constexpr uint32_t SEG_MIN = 32;           // entries per accumulation work item (one thread), see auto_seg(); the work-item and overflow buffers are sized for SEG_MIN
 constexpr uint32_t SEG_MAX = 128;
 constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by length 0..seg
+constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2, ERR_TE_EXCEPTIONAL = 4;  // bits of the device error word
 constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
 
 // ------------------------------------------------------------------ device helpers ----
@@ -69,6 +70,8 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ p, uin
 // ---- curve policies: what the curve-agnostic pipeline kernels need from a curve ----
 // Base = affine input point as kept in a 128-byte `bases` record; Pt = bucket point.
 struct G1Dev {
+  static constexpr uint32_t REC_WORDS = 32;  // one base record, 128 bytes
+  static constexpr bool HAS_QUAD = true;     // quad-cooperative additions (g1_add_quad)
   static constexpr uint32_t RAW_WORDS = 24;  // wire: x || y, 48 bytes each
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, ZZ, ZZZ
   static constexpr uint32_t OUT_WORDS = 48;  // a partial-record point: 4 coordinates x 12 u32 (host-tail format)
@@ -77,7 +80,7 @@ struct G1Dev {
   static __device__ __forceinline__ Fp::El to64() { return Fp::from_const(G1Consts::TO64); }
   using Base = G1Affine;
   using Pt = G1XYZZ;
-  static __device__ __forceinline__ void convert(const uint32_t* raw, uint32_t* rec) {
+  static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {  // true: point not representable
     Fp::El x = Fp::to_mont(Fp::from_words<12>(raw));
     Fp::El y = Fp::to_mont(Fp::from_words<12>(raw + 12));
 #pragma unroll
@@ -87,6 +90,7 @@ struct G1Dev {
     }
 #pragma unroll
     for (int j = 26; j < 32; j++) rec[j] = 0;
+    return false;
   }
   static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
     uint32_t w[28];
@@ -99,6 +103,7 @@ struct G1Dev {
     }
     return p;
   }
+  static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // every case is handled inside the formulas
   static __device__ __forceinline__ Pt identity() { return G1::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return G1::madd(a, q, negq); }  // a + q or a - q
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return G1::add(a, b); }
@@ -125,6 +130,8 @@ struct G1Dev {
 };
 
 struct EdDev {
+  static constexpr uint32_t REC_WORDS = 32;
+  static constexpr bool HAS_QUAD = false;
   static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
   static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
   static constexpr uint32_t OUT_WORDS = 32;  // a partial-record point: 4 coordinates x 8 u32 (host-tail format)
@@ -134,7 +141,7 @@ struct EdDev {
   using Base = Ed::Base;
   using Pt = Ed::Ext;
   // record: (y - x)[9] (y + x)[9] (2d x y)[9] pad[5]
-  static __device__ __forceinline__ void convert(const uint32_t* raw, uint32_t* rec) {
+  static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
     Fq::El x = Fq::to_mont(Fq::from_words<8>(raw));
     Fq::El y = Fq::to_mont(Fq::from_words<8>(raw + 8));
     Base b = Ed::make_base(x, y);
@@ -146,6 +153,7 @@ struct EdDev {
     }
 #pragma unroll
     for (int j = 27; j < 32; j++) rec[j] = 0;
+    return false;
   }
   static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
     uint32_t w[28];
@@ -160,6 +168,7 @@ struct EdDev {
     return p;
   }
 
+  static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // complete addition law
   static __device__ __forceinline__ Pt identity() { return Ed::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Ed::madd(a, Ed::cneg(q, negq)); }
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return Ed::add(a, b); }
@@ -180,6 +189,70 @@ struct EdDev {
       p.y.l[j] = w[9 + j];
       p.t.l[j] = w[18 + j];
       p.z.l[j] = w[27 + j];
+    }
+    return p;
+  }
+};
+
+// BLS12-377 G1 in twisted Edwards form (csrc/te377.hpp): 256-byte records (Y-X, Y+X, 2dT, 2Z), extended buckets.
+struct TeDev {
+  static constexpr uint32_t REC_WORDS = 64;
+  static constexpr bool HAS_QUAD = false;
+  static constexpr uint32_t RAW_WORDS = 24;
+  static constexpr uint32_t PT_WORDS = 52;   // X, Y, T, Z
+  static constexpr uint32_t OUT_WORDS = 48;
+  using F = Fp;
+  static constexpr uint32_t NL = 13, NW32 = 12;
+  static __device__ __forceinline__ Fp::El to64() { return Fp::from_const(G1Consts::TO64); }
+  using Base = Te377::PBase;
+  using Pt = Te377::Ext;
+  static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
+    const Base b = Te377::from_wire(raw, raw + 12, false);
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      rec[j] = b.ymx.l[j];
+      rec[13 + j] = b.ypx.l[j];
+      rec[26 + j] = b.kt.l[j];
+      rec[39 + j] = b.z2.l[j];
+    }
+#pragma unroll
+    for (int j = 52; j < 64; j++) rec[j] = 0;
+    return Fp::is_zero(b.z2);
+  }
+  static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
+    uint32_t w[52];
+    load_words16(bases + (size_t)idx * REC_WORDS, w, 13);
+    Base p;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      p.ymx.l[j] = w[j];
+      p.ypx.l[j] = w[13 + j];
+      p.kt.l[j] = w[26 + j];
+      p.z2.l[j] = w[39 + j];
+    }
+    return p;
+  }
+  static __device__ __forceinline__ bool is_bad(const Pt& p) { return Te377::is_bad(p); }
+  static __device__ __forceinline__ Pt identity() { return Te377::identity(); }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Te377::madd(a, q, negq); }
+  static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return Te377::add(a, b); }
+  static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      w[j] = p.x.l[j];
+      w[13 + j] = p.y.l[j];
+      w[26 + j] = p.t.l[j];
+      w[39 + j] = p.z.l[j];
+    }
+  }
+  static __device__ __forceinline__ Pt from_words(const uint32_t* w) {
+    Pt p;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      p.x.l[j] = w[j];
+      p.y.l[j] = w[13 + j];
+      p.t.l[j] = w[26 + j];
+      p.z.l[j] = w[39 + j];
     }
     return p;
   }
@@ -222,16 +295,16 @@ __device__ __forceinline__ typename CV::Pt load_point_aos(const uint32_t* __rest
 
 // One thread per point: wire record (96 bytes G1, 64 bytes Edwards) -> 128-byte Montgomery record.
 template <class CV>
-__global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n) {
+__global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n, int* __restrict__ err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t w[CV::RAW_WORDS];
   load_words16(raw + i * CV::RAW_WORDS, w, CV::RAW_WORDS / 4);
-  uint32_t o[REC_WORDS];
-  CV::convert(w, o);
-  uint4* dst = reinterpret_cast<uint4*>(bases + i * REC_WORDS);
+  uint32_t o[CV::REC_WORDS];
+  if (CV::convert(w, o)) atomicOr(err, ERR_TE_EXCEPTIONAL);
+  uint4* dst = reinterpret_cast<uint4*>(bases + i * CV::REC_WORDS);
 #pragma unroll
-  for (int k = 0; k < 8; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+  for (int k = 0; k < (int)CV::REC_WORDS / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
 }
 
 // Sort keys: |d| in 0..32768 with the sign carried separately; coarse range = key / 128
@@ -284,6 +357,7 @@ __global__ void __launch_bounds__(256) k_convert_bases_glv(const uint32_t* __res
   const Fp::El x = Fp::to_mont(Fp::from_words<12>(w));
   const Fp::El y = Fp::to_mont(Fp::from_words<12>(w + 12));
   const Fp::El bx = Fp::mul(x, Fp::from_const(G1Consts::BETA));
+  constexpr uint32_t REC_WORDS = G1Dev::REC_WORDS;
   uint32_t o[REC_WORDS];
 #pragma unroll
   for (int j = 0; j < 13; j++) {
@@ -695,8 +769,10 @@ template <class CV, int OCC>
 __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
-                                                       const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG) {
+                                                       const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG,
+                                                       int* __restrict__ err, const int* __restrict__ conv_err) {
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v == 0 && *conv_err) atomicOr(err, *conv_err);  // the table holds a point its coordinate system cannot represent
   if (v >= *work_total) return;
   const WorkItem it = work[v];
   const uint32_t ws = it.row / NB, t = it.row % NB;
@@ -707,6 +783,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   uint32_t k = row_beg + it.seg * seglen;
   const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
   typename CV::Pt acc = CV::identity();
+  bool bad = false;  // an exceptional pair of the twisted Edwards law (te377.hpp): sticky, the caller falls back
   if (k < end) {
     // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
     // entry k is added, so neither the val_idx -> bases address dependency nor the gather
@@ -724,12 +801,14 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
         if (k + 1 < end) e_nn = vi[k + 1];
       }
       acc = CV::madd(acc, cur, (e_cur >> 31) != 0);
+      bad |= CV::is_bad(acc);
       if (!more) break;
       cur = nxt;
       e_cur = e_nxt;
       e_nxt = e_nn;
     }
   }
+  if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
   if (it.seg == 0) {
     store_bucket<CV>(buckets, ws, t, acc);
   } else {
@@ -742,7 +821,8 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
 template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
-                                                             const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG) {
+                                                             const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
+                                                             int* __restrict__ err) {
   const uint32_t count = counters[0];
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
     const uint32_t row = split_rows[i];
@@ -751,7 +831,12 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
     const uint32_t ws = row / NB, t = row % NB;
     typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
     const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::PT_WORDS;
-    for (uint32_t s = 1; s < nseg; s++) acc = CV::add(acc, load_point_aos<CV>(src + (size_t)(s - 1) * CV::PT_WORDS));
+    bool bad = false;
+    for (uint32_t s = 1; s < nseg; s++) {
+      acc = CV::add(acc, load_point_aos<CV>(src + (size_t)(s - 1) * CV::PT_WORDS));
+      bad |= CV::is_bad(acc);
+    }
+    if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
     store_bucket<CV>(buckets, ws, t, acc);
   }
 }
@@ -807,7 +892,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_first(uint32_t* __restrict__ 
 
 // One level r >= 3 of the reduction (see above): (r + 1) lists of NB/2^(r+1) pair-additions.
 template <class CV>
-__global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window) {
+__global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   const uint32_t ws = blockIdx.y;
   if (g >= ops_per_window) return;
@@ -818,7 +903,9 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
   const uint32_t y = x + half;
   typename CV::Pt a = load_bucket<CV>(buckets, ws, x);
   typename CV::Pt b = load_bucket<CV>(buckets, ws, y);
-  store_bucket<CV>(buckets, ws, x, CV::add(a, b));
+  const typename CV::Pt sum = CV::add(a, b);
+  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_EXCEPTIONAL);
+  store_bucket<CV>(buckets, ws, x, sum);
 }
 
 // ---- latency-bound levels: one XYZZ addition per QUAD of lanes ----
@@ -1057,13 +1144,13 @@ struct msm377_ctx {
   bool capture = false;
   bool timing = false;
   uint32_t coop_from = 7;  // first reduction level run with one addition per lane quad (MSM377_COOP_FROM; 15 = never): measured 18-24 -> 13-18 us per level from level 7 on, slower before
-  // GLV front end for the G1 full-MSM entry points: 0 = never, 1 = always, 2 = auto (default).  Interleaved A/B
-  // on one MI355X (tools/ab_knobs.py), plain vs GLV ms per MSM: 2^18 1.39 / 1.24, 2^19 2.08 / 2.00, 2^20 3.56 / 3.51,
-  // 2^21 6.62 / 6.65, 2^22 12.56 / 12.39 -- the halved bucket reduction and host tail are fixed costs, the
-  // accumulation kernel runs at the same rate once the work items are sized by auto_seg().  Auto therefore takes
-  // the GLV path at every size; scalars outside its range rerun on the plain path.
-  int glv_mode = 2;
-  bool bases_glv = false;  // the resident base table holds the phi images too (records n..2n)
+  // GLV front end of the Weierstrass path: 0 = off (default), 1 = on.  phi(P) = [lambda] P holds only for points of
+  // the prime-order subgroup, so it is an opt-in: the caller vouches for the inputs (every protocol use does).
+  // Interleaved A/B on one MI355X (tools/ab_knobs.py), Weierstrass plain vs GLV ms per MSM: 2^18 1.39 / 1.24,
+  // 2^19 2.08 / 2.00, 2^20 3.56 / 3.51, 2^22 12.56 / 12.39 (halved bucket reduction and host tail).
+  int glv_mode = 0;
+  int bases_form = 0;      // TableForm of the resident base table (fixed-base mode)
+  int g1_form = 1;         // G1 full-MSM entry points: 1 = twisted Edwards form (te377.hpp, default), 0 = Weierstrass XYZZ (MSM377_G1_FORM)
   bool last_glv = false;
   bool merge_full_grid = true;  // MSM377_MERGE_FULL_GRID=0: fixed 64-workgroup sweep of the split-row list (A/B knob)
   bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
@@ -1153,7 +1240,8 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
   // main stream, so the previous call's readers of d_bases are done.
   if (n == 0) return MSM377_OK;
   if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream2);
-  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
+  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n, ctx->d_err + 2);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
@@ -1233,21 +1321,21 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
       if (ctx->acc_occ == 4)
         hipLaunchKernelGGL((k_accumulate<CV, 4>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
       else if (ctx->acc_occ == 3)
         hipLaunchKernelGGL((k_accumulate<CV, 3>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (CV::PT_WORDS == G1Dev::PT_WORDS && ctx->merge_quad)
+    if (CV::HAS_QUAD && ctx->merge_quad)
       hipLaunchKernelGGL(k_merge_split_rows_quad, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
                          ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
     else
       hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? rows / 256 : MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
-                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
+                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->capture) {
@@ -1263,10 +1351,10 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     }
     for (uint32_t r = first_level; r < TREE_LEVELS; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
-      if (CV::PT_WORDS == G1Dev::PT_WORDS && r >= ctx->coop_from)
+      if (CV::HAS_QUAD && r >= ctx->coop_from)
         hipLaunchKernelGGL(k_tree_step_quad, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
       else
-        hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
+        hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops, d_err);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, ctx->d_buckets, d_partials, wc);
@@ -1279,7 +1367,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   ctx->last_n = n;
   ctx->last_wc = wc;
   ctx->last_glv = glv;
-  ctx->last_is_g1 = CV::PT_WORDS == G1Dev::PT_WORDS;
+  ctx->last_is_g1 = CV::HAS_QUAD;  // the Weierstrass XYZZ policy (the stage read-backs describe its buckets)
   return MSM377_OK;
 }
 
@@ -1293,7 +1381,7 @@ int finish_windows(msm377_ctx* ctx, int slot) {
       if (hipEventElapsedTime(&ms, ctx->ev[s][0], ctx->ev[s][1]) == hipSuccess) ctx->stage_ms[s] = ms;
     }
   }
-  if (ctx->h_err[slot]) {
+  if (ctx->h_err[slot] & ERR_SCALAR) {
     ctx->err = "a scalar overflows the signed 16-bit window recode (final carry)";
     return MSM377_ESCALAR;
   }
@@ -1308,13 +1396,14 @@ int run_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, uint32_t
 }
 
 constexpr uint32_t GLV_WINDOWS = 8;
-inline bool use_glv(const msm377_ctx* ctx, uint64_t) { return ctx->glv_mode != 0; }  // see msm377_ctx::glv_mode
+inline bool use_glv(const msm377_ctx* ctx, uint64_t) { return ctx->glv_mode == 1; }  // see msm377_ctx::glv_mode
 
 // Base conversion for the G1 entry points: with the GLV front end the table also gets phi(P_i).
 int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool glv) {
   if (!glv) return convert_bases<G1Dev>(ctx, d_raw, n);
   if (n == 0) return MSM377_OK;
   if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream2);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
   hipLaunchKernelGGL(k_convert_bases_glv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream2);
@@ -1322,21 +1411,54 @@ int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool gl
   return MSM377_OK;
 }
 
-// Full G1 MSM of n scalars against ctx->d_bases (already converted or being converted on the side
-// stream).  GLV first when enabled and the table holds the phi images; a scalar outside the GLV
-// range (bit 1 of the error word) reruns the call on the plain 16-window path, whose records
-// 0..n-1 of the table are the plain points either way.
-int g1_full_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, bool glv, uint8_t out_xy[96]) {
-  if (glv) {
+// What ctx->d_bases holds for the G1 entry points.
+enum TableForm { TABLE_XYZZ = 0, TABLE_XYZZ_GLV = 1, TABLE_TE = 2 };
+constexpr int RC_TE_FALLBACK = 1;  // internal: an exceptional case of the twisted Edwards law, rerun on the Weierstrass path
+
+// A prefix of a GLV table (records 0..n-1 = the plain points) serves the plain path; the phi half needs all of it.
+inline int resident_form(const msm377_ctx* ctx, uint64_t n) {
+  return (ctx->bases_form == TABLE_XYZZ_GLV && n != ctx->bases_n) ? TABLE_XYZZ : ctx->bases_form;
+}
+inline int weierstrass_form(const msm377_ctx* ctx, uint64_t n) { return use_glv(ctx, n) ? TABLE_XYZZ_GLV : TABLE_XYZZ; }
+inline int pick_form(const msm377_ctx* ctx, uint64_t n) { return ctx->g1_form == 1 ? TABLE_TE : weierstrass_form(ctx, n); }
+
+int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) {
+  if (form == TABLE_TE) return convert_bases<TeDev>(ctx, d_raw, n);
+  return convert_bases_g1(ctx, d_raw, n, form == TABLE_XYZZ_GLV);
+}
+
+void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
+  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Full G1 MSM of n scalars against ctx->d_bases in form `form` (already converted or being converted on the
+// side stream).  TABLE_TE: 16 windows in twisted Edwards form; RC_TE_FALLBACK when an addition or an input point
+// hit an exceptional case (the caller reconverts and reruns).  TABLE_XYZZ_GLV: the GLV front end; a scalar outside
+// its range (bit 1 of the error word) reruns on the plain 16-window path, whose records 0..n-1 of the table are
+// the plain points either way.
+int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int form, uint8_t out_xy[96]) {
+  if (form == TABLE_TE) {
+    int rc = enqueue_windows<TeDev>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    if (ctx->h_err[0] & ERR_TE_EXCEPTIONAL) return RC_TE_FALLBACK;
+    rc = finish_windows(ctx, 0);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    teh_combine(ctx->h_partials, MSM377_NUM_WINDOWS, out_xy);
+    time_tail(ctx, t0);
+    return MSM377_OK;
+  }
+  if (form == TABLE_XYZZ_GLV) {
     int rc = enqueue_windows<G1Dev>(ctx, d_scalars, n, 0, GLV_WINDOWS, 0, true);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
-    if ((ctx->h_err[0] & 2) == 0) {
+    if ((ctx->h_err[0] & ERR_GLV_RANGE) == 0) {
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
       g1h_combine(ctx->h_partials, GLV_WINDOWS, out_xy);
-      ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      time_tail(ctx, t0);
       return MSM377_OK;
     }
   }
@@ -1344,7 +1466,18 @@ int g1_full_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, bool glv
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   g1h_combine(ctx->h_partials, MSM377_NUM_WINDOWS, out_xy);
-  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  time_tail(ctx, t0);
+  return MSM377_OK;
+}
+
+// The resident table hit an exceptional case of the Edwards law: rebuild it in Weierstrass form from the raw
+// copy kept by msm377_g1_set_bases_device.
+int resident_table_to_weierstrass(msm377_ctx* ctx) {
+  const int form = TABLE_XYZZ;  // points outside the prime-order subgroup: never the GLV front end
+  int rc = convert_table(ctx, ctx->d_raw_points, ctx->bases_n, form);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+  ctx->bases_form = form;
   return MSM377_OK;
 }
 
@@ -1402,6 +1535,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
+  if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
@@ -1413,7 +1547,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
   dalloc((void**)&ctx->d_raw_points, cap * 96);
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
-  dalloc((void**)&ctx->d_bases, 2 * cap * REC_WORDS * 4);  // P_i and, for the GLV front end, phi(P_i)
+  dalloc((void**)&ctx->d_bases, 2 * cap * G1Dev::REC_WORDS * 4);  // 128-byte records of P_i and phi(P_i) (GLV front end), or 256-byte twisted Edwards records of P_i
   dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_range_counts, (size_t)NRANGE * MAX_SORT_BLOCKS * 4);  // chunks * wc <= MAX_SORT_BLOCKS
   dalloc((void**)&ctx->d_region_base, (size_t)MSM377_NUM_WINDOWS * (NRANGE + 1) * 4);
@@ -1427,7 +1561,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 1) * PT_WORDS * 4);
-  dalloc((void**)&ctx->d_err, 2 * sizeof(int));
+  dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
   for (int k = 0; ok && k < 2; k++) ok = ok && hipEventCreateWithFlags(&ctx->done_ev[k], hipEventDisableTiming) == hipSuccess;
@@ -1478,10 +1612,15 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
-  const bool glv = use_glv(ctx, n);
-  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, glv);
+  int form = pick_form(ctx, n);
+  rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
   if (rc) return rc;
-  return g1_full_msm(ctx, (const uint32_t*)d_scalars, n, glv, out_xy);
+  rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
+  if (rc != RC_TE_FALLBACK) return rc;
+  form = TABLE_XYZZ;  // an exceptional case means points outside the prime-order subgroup: never the GLV front end
+  rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
+  if (rc) return rc;
+  return g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
 }
 
 int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
@@ -1553,12 +1692,15 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const bool glv = use_glv(ctx, n);
-  rc = convert_bases_g1(ctx, (const uint32_t*)d_points, n, glv);
+  const int form = pick_form(ctx, n);
+  rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
   if (rc) return rc;
+  // raw copy for the (never expected) fallback from the Edwards form: see resident_table_to_weierstrass
+  if (form == TABLE_TE && d_points != ctx->d_raw_points)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, d_points, n * 96, hipMemcpyDeviceToDevice, ctx->stream2));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   ctx->bases_n = n;
-  ctx->bases_glv = glv;
+  ctx->bases_form = form;
   return MSM377_OK;
 }
 
@@ -1587,7 +1729,11 @@ int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint
     (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream);
     (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream);
   }
-  return g1_full_msm(ctx, (const uint32_t*)d_scalars, n, ctx->bases_glv && n == ctx->bases_n, out_xy);
+  rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, resident_form(ctx, n), out_xy);
+  if (rc != RC_TE_FALLBACK) return rc;
+  rc = resident_table_to_weierstrass(ctx);
+  if (rc) return rc;
+  return g1_table_msm(ctx, (const uint32_t*)d_scalars, n, resident_form(ctx, n), out_xy);
 }
 
 int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy) {
@@ -1604,20 +1750,25 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t* sc = (const uint32_t*)d_scalars;
-  const bool glv = ctx->bases_glv && n == ctx->bases_n;
+  const int form = resident_form(ctx, n);
+  const bool glv = form == TABLE_XYZZ_GLV, te = form == TABLE_TE;
   const uint32_t W = glv ? GLV_WINDOWS : MSM377_NUM_WINDOWS;
   std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
+  bool te_fallback = false;
   // Software pipeline over the batch: while the GPU runs MSM b, the host finishes MSM b-1
   // (Horner + inversion on the other slot's partial records).
   for (uint32_t b = 0; b <= batch; b++) {
-    if (b < batch) {
-      rc = enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
+    if (b < batch && !te_fallback) {
+      rc = te ? enqueue_windows<TeDev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
+              : enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
       if (rc) return rc;
     }
     if (b > 0) {
       const int slot = (int)((b - 1) & 1);
       HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
-      if (glv && (ctx->h_err[slot] & 2)) {
+      if (te && (ctx->h_err[slot] & ERR_TE_EXCEPTIONAL)) te_fallback = true;
+      if (te_fallback) continue;
+      if (glv && (ctx->h_err[slot] & ERR_GLV_RANGE)) {
         redo.push_back(b - 1);
         continue;
       }
@@ -1626,11 +1777,20 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
       }
-      g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
+      if (te)
+        teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
+      else
+        g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
     }
   }
+  if (te_fallback) {  // an exceptional case of the Edwards law somewhere in the batch: Weierstrass table, whole batch again
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = resident_table_to_weierstrass(ctx);
+    if (rc) return rc;
+    return msm377_g1_msm_fixed_base_batch_device(ctx, d_scalars, n, batch, out_xy);
+  }
   for (uint32_t b : redo) {
-    rc = g1_full_msm(ctx, sc + (size_t)b * n * 8, n, false, out_xy + (size_t)96 * b);
+    rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, TABLE_XYZZ, out_xy + (size_t)96 * b);
     if (rc) return rc;
   }
   return MSM377_OK;
@@ -1761,7 +1921,13 @@ int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]) {
 
 int msm377_ctx_set_glv(msm377_ctx* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) return MSM377_EINVAL;
-  ctx->glv_mode = mode;
+  ctx->glv_mode = mode == 1 ? 1 : 0;  // 2 ("the library's choice") is off: see msm377_ctx::glv_mode
+  return MSM377_OK;
+}
+
+int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form) {
+  if (!ctx || form < 0 || form > 1) return MSM377_EINVAL;
+  ctx->g1_form = form;
   return MSM377_OK;
 }
 

@@ -90,6 +90,7 @@ def load_library():
         "msm377_g1_read_stage": (i32, [vp, u32, vp, vp, vp, vp]),
         "msm377_g1_xyzz_to_affine": (i32, [vp, vp]),
         "msm377_ctx_set_glv": (i32, [vp, i32]),
+        "msm377_ctx_set_g1_form": (i32, [vp, i32]),
         "msm377_ctx_set_timing": (i32, [vp, i32]),
         "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
     }
@@ -274,9 +275,15 @@ class MsmEngine:
                 res[k] = v
         return res
 
+    def set_g1_form(self, form="edwards"):
+        """Internal coordinates of the G1 full-MSM entry points: "edwards" / 1 (default, csrc/te377.hpp) or
+        "weierstrass" / 0 (XYZZ behind the GLV front end)."""
+        f = {"edwards": 1, "weierstrass": 0}.get(form, form)
+        self._check(self._lib.msm377_ctx_set_g1_form(self._ctx, int(f)), "msm377_ctx_set_g1_form")
+
     def set_glv(self, mode="auto"):
-        """GLV front end for the G1 full-MSM entry points: False/0 = the plain 16-window path, True/1 = always,
-        "auto"/2 = the library's choice (the default; currently GLV at every size)."""
+        """GLV front end of the Weierstrass form: True/1 = on (the caller vouches that every point lies in the
+        prime-order subgroup), False/0 or "auto"/2 = off (the default)."""
         m = 2 if mode == "auto" else int(mode)
         self._check(self._lib.msm377_ctx_set_glv(self._ctx, m), "msm377_ctx_set_glv")
 
