@@ -85,7 +85,10 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
 /* Window sharding for multi-GPU runs (the reference already treats the
  * 16 window subtasks as independent, submission.ts:199-224).  Computes windows
  * [win_begin, win_begin + win_count) only and writes win_count partial records of
- * MSM377_G1_WINDOW_PARTIAL_BYTES each to the HOST buffer partials_out. */
+ * MSM377_G1_WINDOW_PARTIAL_BYTES each to the HOST buffer partials_out.  The records are opaque: they carry
+ * their own coordinate-system tag (twisted Edwards by default; windows that hit an exceptional case of
+ * that form, and contexts in form 0, produce Weierstrass records), and the combine functions accept any
+ * mixture, so ranks never have to agree on a form. */
 int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n,
                                      uint32_t win_begin, uint32_t win_count, uint8_t* partials_out);
 /* Combine the partial records of all MSM377_NUM_WINDOWS windows (window-major, gathered from
@@ -93,7 +96,8 @@ int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, cons
  * Host-only; needs no context and no device (replaces the CPU tail, submission.ts:290-321). */
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
 
-/* The same sharding behind the GLV front end: MSM377_GLV_WINDOWS = 8 windows over {P_i, phi(P_i)};
+/* The same sharding behind the GLV front end (opt-in, prime-order subgroup points only -- see
+ * msm377_ctx_set_glv; Weierstrass form): MSM377_GLV_WINDOWS = 8 windows over {P_i, phi(P_i)};
  * win_begin / win_count index those 8.  Returns MSM377_EGLVRANGE when a scalar does not split into
  * two 127-bit halves (every rank sees the same scalars, so every rank gets the same verdict and the
  * job repeats on the plain 16-window path).  Halving the windows halves the per-rank fixed costs

@@ -341,6 +341,33 @@ def test_window_sharding_on_one_gpu(engine, oracle, world):
     assert msm.combine_partials(b"".join(parts)) == util.oracle_msm(oracle, pts, ks)
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_window_sharding_with_mixed_record_forms(engine, oracle, world):
+    """Partial records carry their coordinate system (twisted Edwards by default, Weierstrass after a fallback or
+    in form 0): ranks need not agree, the combine accepts any mixture -- including an all-Weierstrass gather and
+    a shard whose own windows hit an exceptional case (a 2-torsion input point)."""
+    n = 1500
+    pts, ks = seeded_inputs(oracle, n, 99)
+    d_p, d_s = dev(pts), dev(ks)
+    exp = util.oracle_msm(oracle, pts, ks)
+    for pattern in ("alternate", "weierstrass"):
+        parts = []
+        try:
+            for r in range(world):
+                b, c = msm.windows_for_rank(r, world)
+                engine.set_g1_form("weierstrass" if (pattern == "weierstrass" or r % 2) else "edwards")
+                parts.append(engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, b, c))
+        finally:
+            default_path(engine)
+        assert msm.combine_partials(b"".join(parts)) == exp, pattern
+    pl = R.decode_points(pts)[:300] + [(R.P - 1, 0)]
+    kl = R.decode_scalars(ks)[:301]
+    pb, sb = R.encode_points(pl), R.encode_scalars(kl)
+    d_p2, d_s2 = dev(pb), dev(sb)
+    parts = [engine.window_partials_device(d_p2.data_ptr(), d_s2.data_ptr(), 301, *msm.windows_for_rank(r, world)) for r in range(world)]
+    assert msm.combine_partials(b"".join(parts)) == R.encode_result(R.msm_naive(pl, kl))
+
+
 @pytest.mark.parametrize("world", [1, 2, 4, 8, 3])
 def test_glv_window_sharding_on_one_gpu(engine, oracle, world):
     """The multi-GPU data path bench.py uses for N > 1: the 8 GLV windows in rank-sized blocks."""
@@ -386,14 +413,22 @@ def test_bucket_reduction_partials_against_oracle_window_sums(engine, oracle):
     n = 3000
     pts, ks = seeded_inputs(oracle, n, 1010)
     d_p, d_s = dev(pts), dev(ks)
-    rec = engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, 0, 16)
     _, ws = util.oracle_msm_params(oracle, pts, ks, 16, 256, want_windows=True)
-    words = np.frombuffer(rec, dtype=np.uint32).reshape(16, 16, 48)
-    for w in (0, 1, 8, 15):
-        g = util.affine_from_record_words(words[w, 0])
-        for l in range(15):
-            g = R.add(g, R.mul(util.affine_from_record_words(words[w, 1 + l]), 1 << l))
-        assert R.encode_result(g) == ws[96 * w : 96 * w + 96], w
+    for form in ("edwards", "weierstrass"):  # the records carry their coordinate system in a tag bit
+        engine.set_g1_form(form)
+        try:
+            rec = engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, 0, 16)
+        finally:
+            default_path(engine)
+        words = np.frombuffer(rec, dtype=np.uint32).reshape(16, 16, 48)
+        for w in (0, 1, 8, 15):
+            te = bool(words[w, 0, 11] >> 31)
+            assert te == (form == "edwards")
+            decode = util.affine_from_te_record_words if te else util.affine_from_record_words
+            g = decode(words[w, 0])
+            for l in range(15):
+                g = R.add(g, R.mul(decode(words[w, 1 + l]), 1 << l))
+            assert R.encode_result(g) == ws[96 * w : 96 * w + 96], (form, w)
 
 
 def test_heavily_skewed_scalars_at_scale(engine, oracle):

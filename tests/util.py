@@ -3,6 +3,7 @@ device-format encoders."""
 import ctypes
 import json
 import os
+import sys
 import subprocess
 
 import pyref as R
@@ -153,8 +154,41 @@ def record_point_words(pt, z=1):
     return (_words12(pt[0] * zz * R64 % R.P) + _words12(pt[1] * zzz * R64 % R.P) + _words12(zz * R64 % R.P) + _words12(zzz * R64 % R.P))
 
 
+_TE = None
+
+
+def te_params():
+    """Constants of the twisted Edwards form of G1 (tools/gen_consts.py te_params: s, c, d)."""
+    global _TE
+    if _TE is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_consts
+
+        _TE = gen_consts.te_params()
+    return _TE
+
+
+def affine_from_te_record_words(words):
+    """A twisted Edwards partial-record point (X, Y, T, Z; csrc/te377.hpp) -> Weierstrass affine point via Python ints."""
+    ri = pow(R64, -1, R.P)
+    w = [int(x) for x in words]
+    w[11] &= 0x7FFFFFFF  # the record's coordinate-system tag (fp64_host.hpp TE_RECORD_TAG)
+    X, Y, T, Z = (sum(w[12 * c + i] << (32 * i) for i in range(12)) * ri % R.P for c in range(4))
+    assert Z != 0 and (X * Y - T * Z) % R.P == 0, "extended-coordinate invariant T Z = X Y violated"
+    te = te_params()
+    zi = pow(Z, -1, R.P)
+    xe, ye = X * zi % R.P, Y * zi % R.P
+    assert (-xe * xe + ye * ye - 1 - te["d"] * xe * xe * ye * ye) % R.P == 0, "not on the Edwards curve"
+    if xe == 0:
+        return None if ye == 1 else (R.P - 1, 0)
+    u = (1 + ye) * pow(1 - ye, -1, R.P) % R.P
+    v = te["c"] * u * pow(xe, -1, R.P) % R.P
+    si = pow(te["s"], -1, R.P)
+    return ((u * si - 1) % R.P, v * si % R.P)
+
+
 def affine_from_record_words(words):
-    """Inverse of record_point_words via Python ints."""
+    """Inverse of record_point_words via Python ints (either coordinate system, told apart by the caller's window tag)."""
     ri = pow(R64, -1, R.P)
     X, Y, ZZ, ZZZ = (sum(int(w) << (32 * i) for i, w in enumerate(words[12 * c : 12 * c + 12])) * ri % R.P for c in range(4))
     if ZZ == 0:

@@ -249,17 +249,19 @@ inline void g1h_to_wire(const G1H::XYZZ& p, uint8_t out[96]) {
 // double-and-add over bit positions b = 16 w + l (16 windows on the plain path, 8 behind the GLV
 // front end).  partials layout: [window][point][48 words], point 0 =
 // Sum_w, point 1 + l = Plane_{w,l}.
-inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+inline G1H::XYZZ g1h_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
   G1H::XYZZ acc = G1H::identity();
   for (int b = 16 * num_windows - 1; b >= 0; b--) {
     acc = G1H::dbl(acc);
     const int w = b >> 4, l = b & 15;
+    if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
     if (l < 15) acc = G1H::add(acc, g1h_from_record_words(base + (size_t)(1 + l) * 48));
     if (l == 0) acc = G1H::add(acc, g1h_from_record_words(base));
   }
-  g1h_to_wire(acc, out);
+  return acc;
 }
+inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) { g1h_to_wire(g1h_horner(partials, num_windows), out); }
 
 // ---- G1 tail in twisted Edwards form (csrc/te377.hpp) ----
 struct TeK64 {
@@ -267,9 +269,16 @@ struct TeK64 {
 };
 using TeH = EdT<Fp64, TeK64>;
 
+// A window's partial record (16 points x 48 words) carries its coordinate system in the top bit of word 11 of
+// its first coordinate (values are < 2^377, the bit is otherwise zero): set = twisted Edwards (X, Y, T, Z),
+// clear = Weierstrass (X, Y, ZZ, ZZZ).  Lets a sharded MSM mix windows that fell back to the Weierstrass path.
+constexpr uint32_t TE_RECORD_TAG = 0x80000000u;
+inline bool window_record_is_te(const uint32_t* window_record) { return (window_record[11] & TE_RECORD_TAG) != 0; }
+
 inline TeH::Ext teh_from_record_words(const uint32_t* w48) {  // X, Y, T, Z as 12 u32 words each, host Montgomery form
   TeH::Ext p;
   p.x = Fp64::from_words32(w48);
+  p.x.v[5] &= ~((uint64_t)TE_RECORD_TAG << 32);
   p.y = Fp64::from_words32(w48 + 12);
   p.t = Fp64::from_words32(w48 + 24);
   p.z = Fp64::from_words32(w48 + 36);
@@ -298,16 +307,43 @@ inline void teh_to_wire(const TeH::Ext& p, uint8_t out[96]) {
   Fp64::to_wire(y, out + 48);
 }
 // Same Horner as g1h_combine over Edwards partial records.
-inline void teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
   TeH::Ext acc = TeH::identity();
   for (int b = 16 * num_windows - 1; b >= 0; b--) {
     acc = TeH::dbl(acc);
     const int w = b >> 4, l = b & 15;
+    if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
     if (l < 15) acc = TeH::add(acc, teh_from_record_words(base + (size_t)(1 + l) * 48));
     if (l == 0) acc = TeH::add(acc, teh_from_record_words(base));
   }
-  teh_to_wire(acc, out);
+  return acc;
+}
+inline void teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) { teh_to_wire(teh_horner(partials, num_windows), out); }
+
+// Partial records of either kind, window by window (see TE_RECORD_TAG).  All of one kind: one Horner chain.  Mixed
+// (some ranks of a sharded MSM fell back to the Weierstrass path): one chain per kind over its own windows, the
+// Edwards sum is mapped back to the Weierstrass curve and the two sums are added there.
+inline void g1_combine_tagged(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+  uint32_t te_mask = 0;
+  for (int w = 0; w < num_windows; w++)
+    if (window_record_is_te(partials + (size_t)w * 16 * 48)) te_mask |= 1u << w;
+  const uint32_t all = num_windows >= 32 ? 0xffffffffu : ((1u << num_windows) - 1u);
+  if (te_mask == all) return teh_combine(partials, num_windows, out);
+  if (te_mask == 0) return g1h_combine(partials, num_windows, out);
+  uint8_t te_wire[96];
+  const TeH::Ext te_sum = teh_horner(partials, num_windows, all & ~te_mask);
+  G1H::XYZZ acc = g1h_horner(partials, num_windows, te_mask);
+  if (!(Fp64::is_zero(te_sum.x) && Fp64::is_zero(Fp64::sub(te_sum.y, te_sum.z)))) {  // not the identity
+    teh_to_wire(te_sum, te_wire);
+    uint32_t w[24];
+    memcpy(w, te_wire, 96);
+    G1H::Affine q;
+    q.x = Fp64::mul(Fp64::from_words32(w), Fp64::from_const(G1Consts64::R2));
+    q.y = Fp64::mul(Fp64::from_words32(w + 12), Fp64::from_const(G1Consts64::R2));
+    acc = G1H::madd(acc, q);
+  }
+  g1h_to_wire(acc, out);
 }
 
 // ---- Edwards tail ----

@@ -71,7 +71,8 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ p, uin
 // Base = affine input point as kept in a 128-byte `bases` record; Pt = bucket point.
 struct G1Dev {
   static constexpr uint32_t REC_WORDS = 32;  // one base record, 128 bytes
-  static constexpr bool HAS_QUAD = true;     // quad-cooperative additions (g1_add_quad)
+  static constexpr bool HAS_QUAD = true;     // quad-cooperative additions (add_quad below)
+  static constexpr bool IS_XYZZ = true;
   static constexpr uint32_t RAW_WORDS = 24;  // wire: x || y, 48 bytes each
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, ZZ, ZZZ
   static constexpr uint32_t OUT_WORDS = 48;  // a partial-record point: 4 coordinates x 12 u32 (host-tail format)
@@ -132,6 +133,7 @@ struct G1Dev {
 struct EdDev {
   static constexpr uint32_t REC_WORDS = 32;
   static constexpr bool HAS_QUAD = false;
+  static constexpr bool IS_XYZZ = false;
   static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
   static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
   static constexpr uint32_t OUT_WORDS = 32;  // a partial-record point: 4 coordinates x 8 u32 (host-tail format)
@@ -197,7 +199,8 @@ struct EdDev {
 // BLS12-377 G1 in twisted Edwards form (csrc/te377.hpp): 256-byte records (Y-X, Y+X, 2dT, 2Z), extended buckets.
 struct TeDev {
   static constexpr uint32_t REC_WORDS = 64;
-  static constexpr bool HAS_QUAD = false;
+  static constexpr bool HAS_QUAD = true;
+  static constexpr bool IS_XYZZ = false;
   static constexpr uint32_t RAW_WORDS = 24;
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, T, Z
   static constexpr uint32_t OUT_WORDS = 48;
@@ -966,8 +969,35 @@ __device__ __forceinline__ G1XYZZ g1_add_quad(const G1XYZZ& a, const G1XYZZ& b, 
   return o;
 }
 
+__device__ __forceinline__ G1XYZZ add_quad(const G1XYZZ& a, const G1XYZZ& b, uint32_t q) { return g1_add_quad(a, b, q); }
+__device__ __forceinline__ Fp::El coord4(uint32_t q, const G1XYZZ& p) { return sel4(q, p.x, p.y, p.zz, p.zzz); }
+
+// The same for the twisted Edwards form (te377.hpp add): 3 rounds instead of 9 multiplications.
+//   1: A = (Y1-X1)(Y2-X2) | B = (Y1+X1)(Y2+X2) | T1 T2 | Z1 Z2
+//   2: C = 2d (T1 T2)   (every lane: no exchange needed)
+//   3: X3 = E F | Y3 = H G | T3 = H E | Z3 = F G           -- the coordinate lane q stores
+__device__ __forceinline__ Te377::Ext add_quad(const Te377::Ext& a, const Te377::Ext& b, uint32_t q) {
+  using K = G1Consts;
+  const Fp::El m1 = Fp::mul_lz(sel4(q, Fp::norm(Fp::add_kp_sub(a.y, K::KP2, a.x)), Fp::norm(Fp::add_lz(a.y, a.x)), a.t, a.z),
+                               sel4(q, Fp::norm(Fp::add_kp_sub(b.y, K::KP2, b.x)), Fp::norm(Fp::add_lz(b.y, b.x)), b.t, b.z));
+  const Fp::El pa = quad_bcast<0>(m1), pb = quad_bcast<1>(m1), tt = quad_bcast<2>(m1), zz = quad_bcast<3>(m1);
+  const Fp::El c = Fp::mul_lz(tt, Fp::from_const(K::TE_2D));
+  const Fp::El d = Fp::add_lz(zz, zz);
+  const Fp::El e = Fp::norm(Fp::add_kp_sub(pb, K::KP2, pa)), f = Fp::norm(Fp::add_kp_sub(d, K::KP2, c));
+  const Fp::El g = Fp::norm(Fp::add_lz(d, c)), h = Fp::add_lz(pb, pa);
+  const Fp::El m3 = Fp::mul_lz(sel4(q, e, h, h, f), sel4(q, f, g, e, g));
+  Te377::Ext o;
+  o.x = quad_bcast<0>(m3);
+  o.y = quad_bcast<1>(m3);
+  o.t = quad_bcast<2>(m3);
+  o.z = quad_bcast<3>(m3);
+  return o;
+}
+__device__ __forceinline__ Fp::El coord4(uint32_t q, const Te377::Ext& p) { return sel4(q, p.x, p.y, p.t, p.z); }
+
 // One reduction level r (same index scheme as k_tree_step) with a quad per addition.
-__global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window) {
+template <class CV>
+__global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
   const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   const uint32_t g = gid >> 2, q = threadIdx.x & 3;
   const uint32_t ws = blockIdx.y;
@@ -976,18 +1006,21 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   const uint32_t oi = g / half, kk = g % half;
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
   const uint32_t x = lo + kk, y = x + half;
-  const G1XYZZ sum = g1_add_quad(load_bucket<G1Dev>(buckets, ws, x), load_bucket<G1Dev>(buckets, ws, y), q);
+  const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, ws, x), load_bucket<CV>(buckets, ws, y), q);
+  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_EXCEPTIONAL);
   // each lane stores one coordinate
-  const Fp::El c = sel4(q, sum.x, sum.y, sum.zz, sum.zzz);
-  uint32_t* base = buckets + ((size_t)ws * G1Dev::PT_WORDS + 13 * q) * NB + x;
+  const Fp::El c = coord4(q, sum);
+  uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + 13 * q) * NB + x;
 #pragma unroll
   for (int j = 0; j < 13; j++) base[(size_t)j * NB] = c.l[j];
 }
 
-// Quad per split row: bucket += its overflow partials (G1).
+// Quad per split row: bucket += its overflow partials.
+template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
-                                                                  const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG) {
+                                                                  const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
+                                                                  int* __restrict__ err) {
   const uint32_t count = counters[0];
   const uint32_t q = threadIdx.x & 3;
   for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {
@@ -995,16 +1028,19 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
     const uint32_t len = row_len(row_ptr, row);
     const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row / NB, t = row % NB;
-    G1XYZZ acc = load_bucket<G1Dev>(buckets, ws, t);
-    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * G1Dev::PT_WORDS;
-    G1XYZZ nxt = load_point_aos<G1Dev>(src);
+    typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
+    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::PT_WORDS;
+    typename CV::Pt nxt = load_point_aos<CV>(src);
+    bool bad = false;
     for (uint32_t s = 1; s < nseg; s++) {
-      const G1XYZZ cur = nxt;
-      if (s + 1 < nseg) nxt = load_point_aos<G1Dev>(src + (size_t)s * G1Dev::PT_WORDS);
-      acc = g1_add_quad(acc, cur, q);
+      const typename CV::Pt cur = nxt;
+      if (s + 1 < nseg) nxt = load_point_aos<CV>(src + (size_t)s * CV::PT_WORDS);
+      acc = add_quad(acc, cur, q);
+      bad |= CV::is_bad(acc);
     }
-    const Fp::El c = sel4(q, acc.x, acc.y, acc.zz, acc.zzz);
-    uint32_t* base = buckets + ((size_t)ws * G1Dev::PT_WORDS + 13 * q) * NB + t;
+    if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
+    const Fp::El c = coord4(q, acc);
+    uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + 13 * q) * NB + t;
 #pragma unroll
     for (int j = 0; j < 13; j++) base[(size_t)j * NB] = c.l[j];
   }
@@ -1330,10 +1366,15 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
                            ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (CV::HAS_QUAD && ctx->merge_quad)
-      hipLaunchKernelGGL(k_merge_split_rows_quad, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
-                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG);
-    else
+    bool merged = false;
+    if constexpr (CV::HAS_QUAD) {
+      if (ctx->merge_quad) {
+        hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets,
+                           counters, ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err);
+        merged = true;
+      }
+    }
+    if (!merged)
       hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? rows / 256 : MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
                          ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err);
     HIP_TRY(ctx, hipGetLastError());
@@ -1351,9 +1392,14 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     }
     for (uint32_t r = first_level; r < TREE_LEVELS; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
-      if (CV::HAS_QUAD && r >= ctx->coop_from)
-        hipLaunchKernelGGL(k_tree_step_quad, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops);
-      else
+      bool done = false;
+      if constexpr (CV::HAS_QUAD) {
+        if (r >= ctx->coop_from) {
+          hipLaunchKernelGGL(k_tree_step_quad<CV>, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops, d_err);
+          done = true;
+        }
+      }
+      if (!done)
         hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops, d_err);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -1367,7 +1413,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   ctx->last_n = n;
   ctx->last_wc = wc;
   ctx->last_glv = glv;
-  ctx->last_is_g1 = CV::HAS_QUAD;  // the Weierstrass XYZZ policy (the stage read-backs describe its buckets)
+  ctx->last_is_g1 = CV::IS_XYZZ;  // the stage read-backs describe the Weierstrass XYZZ buckets
   return MSM377_OK;
 }
 
@@ -1819,6 +1865,22 @@ int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, cons
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
+  if (ctx->g1_form == 1) {  // twisted Edwards form; records tagged (fp64_host.hpp TE_RECORD_TAG)
+    rc = convert_bases<TeDev>(ctx, (const uint32_t*)d_points, n);
+    if (rc) return rc;
+    rc = enqueue_windows<TeDev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count, 0);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    if ((ctx->h_err[0] & ERR_TE_EXCEPTIONAL) == 0) {
+      rc = finish_windows(ctx, 0);
+      if (rc) return rc;
+      memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+      for (uint32_t w = 0; w < win_count; w++)
+        reinterpret_cast<uint32_t*>(partials_out)[(size_t)w * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS + 11] |= TE_RECORD_TAG;
+      return MSM377_OK;
+    }
+    // an exceptional case of the Edwards law in THESE windows: they alone rerun below, untagged
+  }
   rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
   rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count);
@@ -1859,13 +1921,13 @@ int msm377_g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, 
 
 int msm377_g1_combine_window_partials(const uint8_t* partials, uint32_t num_windows, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3) || num_windows == 0 || num_windows > MSM377_NUM_WINDOWS) return MSM377_EINVAL;
-  g1h_combine(reinterpret_cast<const uint32_t*>(partials), (int)num_windows, out_xy);
+  g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), (int)num_windows, out_xy);
   return MSM377_OK;
 }
 
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
-  g1h_combine(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy);
+  g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy);
   return MSM377_OK;
 }
 
