@@ -56,7 +56,7 @@ def pmc_traffic_bytes(log_n):
     for the workload the passes were taken on (2^20); None otherwise or when no summary is committed."""
     if log_n != 20:
         return None
-    for tag in ("r01_final", "r01_c"):
+    for tag in ("r01_te",):  # passes taken on the current default path (twisted Edwards form)
         path = os.path.join(ROOT, "profiles", tag, "pmc_summary.json")
         if os.path.exists(path):
             with open(path) as f:
