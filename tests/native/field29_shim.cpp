@@ -109,6 +109,20 @@ int shim_te_sum(const uint32_t* q24s, const uint8_t* negs, uint32_t count, uint3
   teh_to_wire(te_to_host(total), out96);
   return bad;
 }
+// the same sum through the affine records of resident tables (affine_from_wire + madd_affine, 7 products)
+int shim_te_sum_affine(const uint32_t* q24s, const uint8_t* negs, uint32_t count, uint8_t* out96) {
+  int bad = 0;
+  Te377::Ext acc = Te377::identity();
+  for (uint32_t k = 0; k < count; k++) {
+    bool b0;
+    const Te377::ABase b = Te377::affine_from_wire(q24s + 24 * k, q24s + 24 * k + 12, b0);
+    bad |= b0;
+    acc = Te377::madd_affine(acc, b, negs[k] != 0);
+    bad |= Te377::is_bad(acc);
+  }
+  teh_to_wire(te_to_host(acc), out96);
+  return bad;
+}
 // [k] P on the host tail's field (TeH doubling and addition), P given in wire format
 void shim_teh_scalar_mul(const uint32_t* q24, const uint32_t* k8, uint8_t* out96) {
   const Te377::PBase b = Te377::from_wire(q24, q24 + 12, false);

@@ -177,6 +177,10 @@ def test_twisted_edwards_form_of_g1(shim):
                 pt = R.mul(pt, 0x8508C00000000001 ** 2 - 1)  # phi(P) = [LAMBDA] P
             exp = R.add(exp, R.neg(pt) if ng else pt)
         assert out.raw == R.encode_result(exp), trial
+        if not phi:  # affine records of resident tables: same sum with 7-product additions
+            out2 = ctypes.create_string_buffer(96)
+            assert shim.shim_te_sum_affine(q, (ctypes.c_uint8 * count)(*negs), count, out2) == 0
+            assert out2.raw == out.raw
         words = list(ext)
         for c in range(4):  # stored coordinates: lazy products, carry-normalised, below p + 2^354
             assert all(w < (1 << 29) for w in words[13 * c : 13 * c + 13])

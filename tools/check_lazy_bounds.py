@@ -206,6 +206,11 @@ def main():
     c = mul_lz(mul_lz(PT, PT, "te add T1T2"), canonical, "te add C")
     d = mul_lz(PZ, PZ, "te add D")
     te_finish(a, b, c, add_lz(d, d, "te add 2D"), "te add")
+    # madd_affine: A, B, C as in madd, D = 2 Z1 limb-wise
+    a = mul_lz(add_kp_sub(PY, "KP2", 2, PX, "te amadd Y-X"), canonical, "te amadd A")
+    b = mul_lz(add_lz(PY, PX, "te amadd Y+X"), canonical, "te amadd B")
+    c = mul_lz(kp_sub("KP2", 2, canonical, "te amadd -kt"), PT, "te amadd C")
+    te_finish(a, b, c, add_lz(PZ, PZ, "te amadd 2Z"), "te amadd")
 
     # canonical operations on stored (lazy) coordinates: mul() = reduce_once(mul_lz()) needs mul_lz < 2p
     mul_lz(X1, canonical, "gather X*TO64")

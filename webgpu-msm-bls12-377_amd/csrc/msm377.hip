@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -261,6 +262,41 @@ struct TeDev {
   }
 };
 
+// Affine twisted Edwards records for RESIDENT bases (fixed-base mode): one field inversion per point at
+// msm377_g1_set_bases time buys 7 instead of 8 products per bucket addition and 160-byte records.  Only the
+// base-facing half of the policy differs; buckets, reduction and tail are TeDev's.
+struct TeAffBase {
+  static constexpr uint32_t REC_WORDS = 40;  // (y-x)[13] (y+x)[13] (2dxy)[13] pad[1]
+  static constexpr uint32_t RAW_WORDS = 24;
+  using Base = Te377::ABase;
+  using Pt = Te377::Ext;
+  static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
+    bool bad;
+    const Base b = Te377::affine_from_wire(raw, raw + 12, bad);
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      rec[j] = b.ymx.l[j];
+      rec[13 + j] = b.ypx.l[j];
+      rec[26 + j] = b.kt.l[j];
+    }
+    rec[39] = 0;
+    return bad;
+  }
+  static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
+    uint32_t w[40];
+    load_words16(bases + (size_t)idx * REC_WORDS, w, 10);
+    Base p;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+      p.ymx.l[j] = w[j];
+      p.ypx.l[j] = w[13 + j];
+      p.kt.l[j] = w[26 + j];
+    }
+    return p;
+  }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Te377::madd_affine(a, q, negq); }
+};
+
 // Limb-major bucket array: word j of bucket t of window slot ws at [(ws * PT_WORDS + j) * NB + t].
 template <class CV>
 __device__ __forceinline__ typename CV::Pt load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
@@ -297,7 +333,7 @@ __device__ __forceinline__ typename CV::Pt load_point_aos(const uint32_t* __rest
 // ------------------------------------------------------------------------ kernels ----
 
 // One thread per point: wire record (96 bytes G1, 64 bytes Edwards) -> 128-byte Montgomery record.
-template <class CV>
+template <class CV>  // CV: a curve policy or a base policy (RAW_WORDS, REC_WORDS, convert)
 __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n, int* __restrict__ err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -768,7 +804,7 @@ __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restric
 }
 
 // One thread per work item.  OCC = waves per SIMD the register allocator must allow.
-template <class CV, int OCC>
+template <class CV, int OCC, class BP = CV>  // BP: where the input points come from (CV itself, or TeAffBase)
 __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
@@ -793,17 +829,17 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
     // latency stalls the wave.
     uint32_t e_cur = vi[k];
     uint32_t e_nxt = (k + 1 < end) ? vi[k + 1] : 0u;
-    typename CV::Base cur = CV::load_base(bases, e_cur & 0x7fffffffu);
+    typename BP::Base cur = BP::load_base(bases, e_cur & 0x7fffffffu);
     while (true) {
       k++;
       const bool more = k < end;
-      typename CV::Base nxt = cur;
+      typename BP::Base nxt = cur;
       uint32_t e_nn = 0u;
       if (more) {
-        nxt = CV::load_base(bases, e_nxt & 0x7fffffffu);
+        nxt = BP::load_base(bases, e_nxt & 0x7fffffffu);
         if (k + 1 < end) e_nn = vi[k + 1];
       }
-      acc = CV::madd(acc, cur, (e_cur >> 31) != 0);
+      acc = BP::madd(acc, cur, (e_cur >> 31) != 0);
       bad |= CV::is_bad(acc);
       if (!more) break;
       cur = nxt;
@@ -1186,6 +1222,7 @@ struct msm377_ctx {
   // 2^19 2.08 / 2.00, 2^20 3.56 / 3.51, 2^22 12.56 / 12.39 (halved bucket reduction and host tail).
   int glv_mode = 0;
   int bases_form = 0;      // TableForm of the resident base table (fixed-base mode)
+  bool te_affine_table = true;  // MSM377_TE_AFFINE_TABLE=0: resident Edwards tables stay projective (A/B knob)
   int g1_form = 1;         // G1 full-MSM entry points: 1 = twisted Edwards form (te377.hpp, default), 0 = Weierstrass XYZZ (MSM377_G1_FORM)
   bool last_glv = false;
   bool merge_full_grid = true;  // MSM377_MERGE_FULL_GRID=0: fixed 64-workgroup sweep of the split-row list (A/B knob)
@@ -1303,7 +1340,7 @@ constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POI
 // Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
 // the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
 // Nothing here waits for the GPU.
-template <class CV>
+template <class CV, class BP = CV>
 int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false) {
   // GLV front end: n_scalars scalars become 2 n_scalars (point, half-scalar) columns over 8 windows.
   const uint64_t n = glv ? 2 * n_scalars : n_scalars;
@@ -1355,7 +1392,10 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->bases_ready, 0));
     {
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
-      if (ctx->acc_occ == 4)
+      if constexpr (!std::is_same<BP, CV>::value)
+        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
+                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
+      else if (ctx->acc_occ == 4)
         hipLaunchKernelGGL((k_accumulate<CV, 4>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
                            ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
       else if (ctx->acc_occ == 3)
@@ -1458,7 +1498,7 @@ int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool gl
 }
 
 // What ctx->d_bases holds for the G1 entry points.
-enum TableForm { TABLE_XYZZ = 0, TABLE_XYZZ_GLV = 1, TABLE_TE = 2 };
+enum TableForm { TABLE_XYZZ = 0, TABLE_XYZZ_GLV = 1, TABLE_TE = 2, TABLE_TE_AFFINE = 3 };
 constexpr int RC_TE_FALLBACK = 1;  // internal: an exceptional case of the twisted Edwards law, rerun on the Weierstrass path
 
 // A prefix of a GLV table (records 0..n-1 = the plain points) serves the plain path; the phi half needs all of it.
@@ -1470,6 +1510,7 @@ inline int pick_form(const msm377_ctx* ctx, uint64_t n) { return ctx->g1_form ==
 
 int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) {
   if (form == TABLE_TE) return convert_bases<TeDev>(ctx, d_raw, n);
+  if (form == TABLE_TE_AFFINE) return convert_bases<TeAffBase>(ctx, d_raw, n);
   return convert_bases_g1(ctx, d_raw, n, form == TABLE_XYZZ_GLV);
 }
 
@@ -1483,8 +1524,9 @@ void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
 // its range (bit 1 of the error word) reruns on the plain 16-window path, whose records 0..n-1 of the table are
 // the plain points either way.
 int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int form, uint8_t out_xy[96]) {
-  if (form == TABLE_TE) {
-    int rc = enqueue_windows<TeDev>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
+  if (form == TABLE_TE || form == TABLE_TE_AFFINE) {
+    int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0)
+                              : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     if (ctx->h_err[0] & ERR_TE_EXCEPTIONAL) return RC_TE_FALLBACK;
@@ -1582,6 +1624,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
@@ -1738,11 +1781,12 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int form = pick_form(ctx, n);
+  int form = pick_form(ctx, n);
+  if (form == TABLE_TE && ctx->te_affine_table) form = TABLE_TE_AFFINE;  // resident: one inversion per point, once
   rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
   if (rc) return rc;
   // raw copy for the (never expected) fallback from the Edwards form: see resident_table_to_weierstrass
-  if (form == TABLE_TE && d_points != ctx->d_raw_points)
+  if ((form == TABLE_TE || form == TABLE_TE_AFFINE) && d_points != ctx->d_raw_points)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, d_points, n * 96, hipMemcpyDeviceToDevice, ctx->stream2));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   ctx->bases_n = n;
@@ -1797,7 +1841,7 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t* sc = (const uint32_t*)d_scalars;
   const int form = resident_form(ctx, n);
-  const bool glv = form == TABLE_XYZZ_GLV, te = form == TABLE_TE;
+  const bool glv = form == TABLE_XYZZ_GLV, te = form == TABLE_TE || form == TABLE_TE_AFFINE;
   const uint32_t W = glv ? GLV_WINDOWS : MSM377_NUM_WINDOWS;
   std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
   bool te_fallback = false;
@@ -1805,8 +1849,9 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
   // (Horner + inversion on the other slot's partial records).
   for (uint32_t b = 0; b <= batch; b++) {
     if (b < batch && !te_fallback) {
-      rc = te ? enqueue_windows<TeDev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
-              : enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
+      rc = form == TABLE_TE_AFFINE ? enqueue_windows<TeDev, TeAffBase>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
+           : te                    ? enqueue_windows<TeDev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
+                                   : enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
       if (rc) return rc;
     }
     if (b > 0) {

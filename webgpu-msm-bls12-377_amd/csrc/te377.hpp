@@ -41,6 +41,9 @@ struct Te377 {
   struct PBase {  // projective input point in precomputed form, canonical coordinates
     El ymx, ypx, kt, z2;  // Y - X, Y + X, 2d T, 2 Z
   };
+  struct ABase {  // affine input point in precomputed form (resident tables): y - x, y + x, 2d x y
+    El ymx, ypx, kt;
+  };
   struct Ext {
     El x, y, t, z;
   };
@@ -72,6 +75,25 @@ struct Te377 {
     return b;
   }
 
+  // The affine form of the same record: one Fermat inversion per point (~450 field products), affordable only
+  // where the table is reused (msm377_g1_set_bases).  bad <=> the map is undefined at this point.
+  static MSM_HD ABase affine_from_wire(const uint32_t* x12, const uint32_t* y12, bool& bad) {
+    const El xr = F::template from_words<12>(x12), yr = F::template from_words<12>(y12);
+    const El u = F::add(F::mul(xr, F::from_const(K::TE_SR)), F::from_const(K::TE_S));
+    const El v = F::mul(yr, F::from_const(K::TE_SR));
+    const El cu = F::add(F::mul(xr, F::from_const(K::TE_CSR)), F::from_const(K::TE_CS));
+    const El up = F::add(u, F::one()), um = F::sub(u, F::one());
+    const El Z = F::mul(v, up);
+    bad = F::is_zero(Z);
+    const El zi = fe_pow<F, K::PM2_NW>(Z, K::PM2_W);
+    const El x = F::mul(F::mul(cu, up), zi), y = F::mul(F::mul(um, v), zi);
+    ABase b;
+    b.ymx = F::sub(y, x);
+    b.ypx = F::add(y, x);
+    b.kt = F::mul(F::mul(x, y), F::from_const(K::TE_2D));
+    return b;
+  }
+
   // A stored coordinate (< p + 2^354, carry-normalised) that is 0 mod p: all limbs zero, or exactly p.
   static MSM_HD bool is_zero_mod_p(const El& a) { return F::is_zero(a) || F::eq(a, F::from_const(K::MOD)); }
   static MSM_HD bool is_bad(const Ext& p) { return is_zero_mod_p(p.z); }
@@ -85,6 +107,14 @@ struct Te377 {
     const El c = F::mul_lz(F::select(neg, F::kp_sub(K::KP2, q.kt), q.kt), p.t);
     const El d = F::mul_lz(p.z, q.z2);
     return finish(a, b, c, d);
+  }
+
+  // The same with an affine input point (Z2 = 1): 7 products; D = 2 Z1 limb-wise.
+  static MSM_HD Ext madd_affine(const Ext& p, const ABase& q, bool neg) {
+    const El a = F::mul_lz(F::add_kp_sub(p.y, K::KP2, p.x), F::select(neg, q.ypx, q.ymx));
+    const El b = F::mul_lz(F::add_lz(p.y, p.x), F::select(neg, q.ymx, q.ypx));
+    const El c = F::mul_lz(F::select(neg, F::kp_sub(K::KP2, q.kt), q.kt), p.t);
+    return finish(a, b, c, F::add_lz(p.z, p.z));
   }
 
   // General addition: 9 products (one of them by the constant 2d).
