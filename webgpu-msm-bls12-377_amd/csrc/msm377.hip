@@ -1230,7 +1230,11 @@ struct msm377_ctx {
   uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
   int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
   bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
-  hipEvent_t ev[MSM377_NUM_STAGES][2] = {};
+  hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
+  hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
+  hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
+  int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
+  uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
 };
 
@@ -1294,14 +1298,16 @@ void identity_wire(uint8_t out[96]) {
   out[48] = 1;
 }
 
-struct StageTimer {
+struct StageTimer {  // HIP events around one stage of one part, on the part's own stream
   msm377_ctx* c;
   int s;
-  StageTimer(msm377_ctx* ctx, int stage) : c(ctx), s(stage) {
-    if (c->timing) (void)hipEventRecord(c->ev[s][0], c->stream);
+  hipStream_t st;
+  uint32_t part;
+  StageTimer(msm377_ctx* ctx, int stage, hipStream_t stream, uint32_t part_) : c(ctx), s(stage), st(stream), part(part_) {
+    if (c->timing) (void)hipEventRecord(c->ev[part][s][0], st);
   }
   ~StageTimer() {
-    if (c->timing) (void)hipEventRecord(c->ev[s][1], c->stream);
+    if (c->timing) (void)hipEventRecord(c->ev[part][s][1], st);
   }
 };
 
@@ -1312,11 +1318,11 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
   // k_accumulate waits for `bases_ready`.  Every entry point ends with a host-side wait for the
   // main stream, so the previous call's readers of d_bases are done.
   if (n == 0) return MSM377_OK;
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream2);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
   hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n, ctx->d_err + 2);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream2);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
   return MSM377_OK;
 }
@@ -1335,98 +1341,121 @@ uint32_t auto_seg(const msm377_ctx* ctx, uint64_t entries, bool glv) {
   return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, SEG_MIN), SEG_MAX);
 }
 
+constexpr uint64_t PIPELINE_MIN_ENTRIES = 1ull << 21;  // (windows x points) below which a call stays in one part
+
 constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot
 
 // Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
 // the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
 // Nothing here waits for the GPU.
-template <class CV, class BP = CV>
-int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false) {
-  // GLV front end: n_scalars scalars become 2 n_scalars (point, half-scalar) columns over 8 windows.
-  const uint64_t n = glv ? 2 * n_scalars : n_scalars;
-  hipStream_t st = ctx->stream;
-  int* d_err = ctx->d_err + slot;
-  uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
-  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
+// One part of a call's windows: window slots [ws0, ws0 + wc) of every window-indexed buffer, windows
+// [wb, wb + wc) of the scalars, on its own stream.
+struct PartView {
+  hipStream_t st;
+  uint32_t part, ws0, wb, wc;
+  size_t work_off, ovf_off;  // first work item / overflow slot of this part
+};
+
+template <class CV, class BP>
+int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint64_t n, const PartView& pv, int* d_err, uint32_t* d_partials, bool glv,
+                 uint32_t sort_blocks) {
+  hipStream_t st = pv.st;
+  const uint32_t wc = pv.wc, part = pv.part;
+  const uint32_t SEG = auto_seg(ctx, (uint64_t)wc * n, glv);  // per launch: each part must fill the GPU on its own
+  uint16_t* digits = ctx->d_digits + (size_t)pv.ws0 * n;
+  uint32_t* range_counts = ctx->d_range_counts + (size_t)part * NRANGE * (MAX_SORT_BLOCKS / 2);
+  uint32_t* region_base = ctx->d_region_base + (size_t)pv.ws0 * (NRANGE + 1);
+  SortElem* sort_temp = ctx->d_sort_temp + (size_t)pv.ws0 * n;
+  uint32_t* row_ptr = ctx->d_row_ptr + (size_t)pv.ws0 * RP;
+  uint32_t* val_idx = ctx->d_val_idx + (size_t)pv.ws0 * n;
+  uint32_t* buckets = ctx->d_buckets + (size_t)pv.ws0 * CV::PT_WORDS * NB;
+  uint32_t* row_ovf_base = ctx->d_row_ovf_base + (size_t)pv.ws0 * NB;
+  uint32_t* split_rows = ctx->d_split_rows + (size_t)pv.ws0 * NB;
+  WorkItem* work = ctx->d_work + pv.work_off;
+  uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::PT_WORDS;
   {
-    StageTimer t(ctx, MSM377_STAGE_DECOMPOSE);
+    StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (glv)
-      hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n_scalars, wb, wc, d_err);
+      hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n_scalars, pv.wb, wc, d_err);
     else
-      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_digits, n, wb, wc, d_err);
+      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err);
     HIP_TRY(ctx, hipGetLastError());
   }
+
   {
-    StageTimer t(ctx, MSM377_STAGE_SORT);
-    uint32_t chunks = MAX_SORT_BLOCKS / wc;
+    StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
+    uint32_t chunks = sort_blocks / wc;
     const uint64_t want = (n + 4095) / 4096;  // at least ~4096 elements per block
     if (chunks > want) chunks = (uint32_t)(want ? want : 1);
     const uint64_t per_chunk = (n + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, ctx->d_digits, ctx->d_range_counts, n, chunks, per_chunk);
+    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, n, chunks, per_chunk);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, ctx->d_range_counts, ctx->d_region_base, chunks);
+    hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, range_counts, region_base, chunks);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_partition, dim3(chunks, wc), dim3(1024), 0, st, ctx->d_digits, ctx->d_range_counts, ctx->d_sort_temp, n, chunks, per_chunk);
+    hipLaunchKernelGGL(k_partition, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, ctx->d_sort_temp, ctx->d_region_base, ctx->d_row_ptr, ctx->d_val_idx, n);
+    hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
-    StageTimer t(ctx, MSM377_STAGE_ACCUMULATE);
+    StageTimer t(ctx, MSM377_STAGE_ACCUMULATE, st, part);
     const uint32_t rows = wc * NB;
-    uint32_t* meta = ctx->d_work_meta;
+    uint32_t* meta = ctx->d_work_meta + (size_t)part * (2 * SEG_BINS + 4);
     uint32_t* work_hist = meta;
     uint32_t* cursor = meta + SEG_BINS;
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
     HIP_TRY(ctx, hipMemsetAsync(meta, 0, (size_t)(2 * SEG_BINS + 4) * 4, st));
-    const uint32_t SEG = auto_seg(ctx, (uint64_t)wc * n, glv);
-    hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, SEG, work_hist, ctx->d_row_ovf_base, counters,
-                       ctx->d_split_rows);
+    hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, row_ptr, rows, SEG, work_hist, row_ovf_base, counters, split_rows);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, ctx->d_row_ptr, rows, SEG, cursor, ctx->d_work);
+    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, row_ptr, rows, SEG, cursor, work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->bases_ready, 0));
+    // The accumulation launches of the two parts run one after the other (the second waits for the first): they
+    // are the power-limited kernels, sharing the GPU would only stretch both.
+    if (part == 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->acc_done, 0));
     {
-      StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL);
+      StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL, st, part);
+      const dim3 grid((unsigned)((max_items + 255) / 256));
       if constexpr (!std::is_same<BP, CV>::value)
-        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2);
       else if (ctx->acc_occ == 4)
-        hipLaunchKernelGGL((k_accumulate<CV, 4>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 4>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2);
       else if (ctx->acc_occ == 3)
-        hipLaunchKernelGGL((k_accumulate<CV, 3>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 3>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2);
       else
-        hipLaunchKernelGGL((k_accumulate<CV, 2>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_val_idx,
-                           ctx->d_bases, ctx->d_buckets, n, ctx->d_work, total, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err, ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2);
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
     bool merged = false;
     if constexpr (CV::HAS_QUAD) {
       if (ctx->merge_quad) {
-        hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets,
-                           counters, ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err);
+        hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
+                           row_ovf_base, ovf, SEG, d_err);
         merged = true;
       }
     }
     if (!merged)
-      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? rows / 256 : MERGE_GRID), dim3(256), 0, st, ctx->d_row_ptr, ctx->d_buckets, counters,
-                         ctx->d_split_rows, ctx->d_row_ovf_base, ctx->d_ovf, SEG, d_err);
+      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? rows / 256 : MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
+                         row_ovf_base, ovf, SEG, d_err);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->capture) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, ctx->d_buckets, (size_t)wc * CV::PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, buckets, (size_t)wc * CV::PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
   }
   {
-    StageTimer t(ctx, MSM377_STAGE_REDUCE);
+    StageTimer t(ctx, MSM377_STAGE_REDUCE, st, part);
     uint32_t first_level = 0;
     if (ctx->reduce_fused) {
-      hipLaunchKernelGGL(k_reduce_first<CV>, dim3(NB / 8 / 256, wc), dim3(256), 0, st, ctx->d_buckets);
+      hipLaunchKernelGGL(k_reduce_first<CV>, dim3(NB / 8 / 256, wc), dim3(256), 0, st, buckets);
       HIP_TRY(ctx, hipGetLastError());
       first_level = 3;
     }
@@ -1435,16 +1464,53 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
       bool done = false;
       if constexpr (CV::HAS_QUAD) {
         if (r >= ctx->coop_from) {
-          hipLaunchKernelGGL(k_tree_step_quad<CV>, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops, d_err);
+          hipLaunchKernelGGL(k_tree_step_quad<CV>, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, buckets, r, ops, d_err);
           done = true;
         }
       }
-      if (!done)
-        hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, ctx->d_buckets, r, ops, d_err);
+      if (!done) hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, buckets, r, ops, d_err);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, ctx->d_buckets, d_partials, wc);
+    hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets,
+                       d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc);
     HIP_TRY(ctx, hipGetLastError());
+  }
+  return MSM377_OK;
+}
+
+// Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
+// the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
+// Nothing here waits for the GPU.
+//
+// Large calls run as TWO parts (half the windows each) on two streams: while the power-limited accumulation
+// kernel of part 0 runs, the GPU also sorts part 1's digit columns and builds its work list (LDS / latency
+// bound), and part 0's merge and bucket reduction (short launches, latency bound from level 5 on) overlap
+// part 1's accumulation.  Only the second part's reduction stays exposed.
+template <class CV, class BP = CV>
+int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false) {
+  // GLV front end: n_scalars scalars become 2 n_scalars (point, half-scalar) columns over 8 windows.
+  const uint64_t n = glv ? 2 * n_scalars : n_scalars;
+  hipStream_t st = ctx->stream;
+  int* d_err = ctx->d_err + slot;
+  uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
+  const uint32_t parts = (ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
+  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
+  PartView pv[2];
+  const uint32_t wc0 = parts == 2 ? (wc + 1) / 2 : wc;
+  pv[0] = PartView{st, 0, 0, wb, wc0, 0, 0};
+  pv[1] = PartView{ctx->stream3, 1, wc0, wb + wc0, wc - wc0, (size_t)wc0 * NB + (size_t)wc0 * n / SEG_MIN + 1, (size_t)wc0 * n / SEG_MIN + 1};
+  if (parts == 2) {
+    HIP_TRY(ctx, hipEventRecord(ctx->part_fork, st));  // after the error word is cleared and everything queued before this call
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->part_fork, 0));
+  }
+  ctx->last_parts = parts;
+  for (uint32_t p = 0; p < parts; p++) {
+    int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS);
+    if (rc) return rc;
+  }
+  if (parts == 2) {
+    HIP_TRY(ctx, hipEventRecord(ctx->part_join, ctx->stream3));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->part_join, 0));
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
                                hipMemcpyDeviceToHost, st));
@@ -1463,8 +1529,12 @@ int finish_windows(msm377_ctx* ctx, int slot) {
   if (ctx->timing) {
     for (int s = 0; s < MSM377_NUM_STAGES; s++) {
       if (s == MSM377_STAGE_TAIL) continue;  // host wall time, set by the caller
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->ev[s][0], ctx->ev[s][1]) == hipSuccess) ctx->stage_ms[s] = ms;
+      double sum = 0.0;  // a pipelined call reports the sum over its two parts (they overlap each other in wall time)
+      for (uint32_t p = 0; p < (s == MSM377_STAGE_CONVERT ? 1u : ctx->last_parts); p++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[p][s][0], ctx->ev[p][s][1]) == hipSuccess) sum += ms;
+      }
+      ctx->stage_ms[s] = sum;
     }
   }
   if (ctx->h_err[slot] & ERR_SCALAR) {
@@ -1488,11 +1558,11 @@ inline bool use_glv(const msm377_ctx* ctx, uint64_t) { return ctx->glv_mode == 1
 int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool glv) {
   if (!glv) return convert_bases<G1Dev>(ctx, d_raw, n);
   if (n == 0) return MSM377_OK;
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream2);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
   hipLaunchKernelGGL(k_convert_bases_glv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream2);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
   return MSM377_OK;
 }
@@ -1624,15 +1694,27 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   const uint64_t cap = max_points;
-  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess;
+  // The main stream outranks the side stream: the base conversion (VALU-heavy, ~0.2 ms) only has to finish before
+  // the accumulation starts, decompose + sort on the main stream are the critical path (k_decompose: 16 us alone,
+  // ~100 us when it competes with the conversion at equal priority).
+  int prio_least = 0, prio_greatest = 0;
+  bool ok = hipSetDevice(device) == hipSuccess;
+  if (ok && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
+  const bool use_prio = getenv("MSM377_STREAM_PRIORITY") ? atoi(getenv("MSM377_STREAM_PRIORITY")) != 0 : true;
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, use_prio ? prio_greatest : prio_least) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
+            hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->part_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->part_join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->acc_done, hipEventDisableTiming) == hipSuccess;
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
   dalloc((void**)&ctx->d_raw_points, cap * 96);
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
@@ -1645,17 +1727,17 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
   dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
-  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_MIN + 1) * sizeof(WorkItem));
-  dalloc((void**)&ctx->d_work_meta, (size_t)(2 * SEG_BINS + 4) * 4);
+  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * sizeof(WorkItem));
+  dalloc((void**)&ctx->d_work_meta, (size_t)2 * (2 * SEG_BINS + 4) * 4);  // one block per pipeline part
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
-  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 1) * PT_WORDS * 4);
+  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * PT_WORDS * 4);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
   for (int k = 0; ok && k < 2; k++) ok = ok && hipEventCreateWithFlags(&ctx->done_ev[k], hipEventDisableTiming) == hipSuccess;
   for (int s = 0; ok && s < MSM377_NUM_STAGES; s++)
-    for (int k = 0; k < 2; k++) ok = ok && hipEventCreate(&ctx->ev[s][k]) == hipSuccess;
+    for (int k = 0; k < 4; k++) ok = ok && hipEventCreate(&ctx->ev[k >> 1][s][k & 1]) == hipSuccess;
   if (!ok) {
     msm377_ctx_destroy(ctx);
     return MSM377_ENOMEM;
@@ -1669,6 +1751,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
                   ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
   for (void* p : bufs)
@@ -1682,8 +1765,12 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
     if (ctx->done_ev[k]) (void)hipEventDestroy(ctx->done_ev[k]);
   for (int s = 0; s < MSM377_NUM_STAGES; s++)
     for (int k = 0; k < 2; k++)
-      if (ctx->ev[s][k]) (void)hipEventDestroy(ctx->ev[s][k]);
+      for (int p = 0; p < 2; p++)
+        if (ctx->ev[p][s][k]) (void)hipEventDestroy(ctx->ev[p][s][k]);
   if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
+  for (hipEvent_t e : {ctx->part_fork, ctx->part_join, ctx->acc_done})
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1702,6 +1789,7 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
   int form = pick_form(ctx, n);
+  // (Queueing the conversion after k_decompose instead was measured: decompose 77 -> 23 us, sort 272 -> 386 us.)
   rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
   if (rc) return rc;
   rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
@@ -1816,8 +1904,8 @@ int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->timing) {  // no conversion in this mode
-    (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][0], ctx->stream);
-    (void)hipEventRecord(ctx->ev[MSM377_STAGE_CONVERT][1], ctx->stream);
+    (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream);
+    (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream);
   }
   rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, resident_form(ctx, n), out_xy);
   if (rc != RC_TE_FALLBACK) return rc;
