@@ -91,6 +91,11 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
  * mixture, so ranks never have to agree on a form. */
 int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n,
                                      uint32_t win_begin, uint32_t win_count, uint8_t* partials_out);
+/* Optional, before the exchange: a rank folds the records of its own win_count CONSECUTIVE windows (in place,
+ * same size, same total: one short Horner chain over them; every point but one becomes the identity), which
+ * leaves the final combine on every rank with its doublings and one addition per rank instead of 16 per
+ * window -- the host tail is a fixed cost that does not shrink with the number of GPUs.  Host-only. */
+int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count);
 /* Combine the partial records of all MSM377_NUM_WINDOWS windows (window-major, gathered from
  * the ranks) into the final affine result: Horner over the windows, one field inversion.
  * Host-only; needs no context and no device (replaces the CPU tail, submission.ts:290-321). */

@@ -58,3 +58,45 @@ def test_combine_against_oracle_window_sums(oracle, golden):
 def test_combine_rejects_wrong_length():
     with pytest.raises(ValueError):
         msm.combine_partials(b"\0" * 100)
+
+
+def te_record(pts16, rnd):
+    import struct
+
+    words = []
+    for i, p in enumerate(pts16):
+        words += util.te_record_point_words(p, rnd.randrange(1, R.P), tag=(i == 0))
+    return struct.pack("<%dI" % len(words), *words)
+
+
+def test_combine_accepts_mixed_record_forms_and_folded_blocks():
+    """Window records carry their coordinate system (csrc/fp64_host.hpp TE_RECORD_TAG): all Edwards, all Weierstrass
+    and any mixture combine to the same point; a rank may first fold its consecutive windows
+    (msm377_g1_fold_window_partials) -- the exchange then carries one real point per rank."""
+    from webgpu_msm_bls12_377_amd.host.engine import WINDOW_PARTIAL_BYTES, fold_partials_bytes
+
+    rnd = random.Random(11)
+    base = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(7)] + [(R.P - 1, 0)]
+    win_pts, expect = [], None
+    for w in range(16):
+        pts16 = [rnd.choice(base + [None, None]) for _ in range(16)]
+        win_pts.append(pts16)
+        g = pts16[0]
+        for l in range(15):
+            g = R.add(g, R.mul(pts16[1 + l], 1 << l))
+        expect = R.add(expect, R.mul(g, 1 << (16 * w)))
+    exp = R.encode_result(expect)
+    for pattern in ("edwards", "weierstrass", "alternate", "blocks"):
+        recs = []
+        for w in range(16):
+            te = {"edwards": True, "weierstrass": False, "alternate": w % 2 == 0, "blocks": (w // 3) % 2 == 0}[pattern]
+            recs.append(te_record(win_pts[w], rnd) if te else record(win_pts[w], rnd))
+        assert msm.combine_partials(b"".join(recs)) == exp, pattern
+        for world in (2, 3, 8, 16):  # every rank folds its own block before the exchange
+            folded = []
+            for r in range(world):
+                b, c = msm.windows_for_rank(r, world)
+                mine = fold_partials_bytes(b"".join(recs[b : b + c]))
+                assert len(mine) == c * WINDOW_PARTIAL_BYTES
+                folded.append(mine)
+            assert msm.combine_partials(b"".join(folded)) == exp, (pattern, world)

@@ -168,6 +168,24 @@ def te_params():
     return _TE
 
 
+def te_record_point_words(pt, z=1, tag=False):
+    """Weierstrass affine point (or None) -> one twisted Edwards partial-record point (X, Y, T, Z as 12 u32 words each,
+    radix-2^384 Montgomery form), scaled by a projective factor z; tag sets the record's coordinate-system bit."""
+    te = te_params()
+    if pt is None:
+        xe, ye = 0, 1
+    elif pt == (R.P - 1, 0):
+        xe, ye = 0, R.P - 1
+    else:
+        u, v = te["s"] * (pt[0] + 1) % R.P, te["s"] * pt[1] % R.P
+        xe, ye = te["c"] * u * pow(v, -1, R.P) % R.P, (u - 1) * pow(u + 1, -1, R.P) % R.P
+    X, Y, T, Z = xe * z % R.P, ye * z % R.P, xe * ye * z % R.P, z % R.P
+    w = _words12(X * R64 % R.P) + _words12(Y * R64 % R.P) + _words12(T * R64 % R.P) + _words12(Z * R64 % R.P)
+    if tag:
+        w[11] |= 0x80000000
+    return w
+
+
 def affine_from_te_record_words(words):
     """A twisted Edwards partial-record point (X, Y, T, Z; csrc/te377.hpp) -> Weierstrass affine point via Python ints."""
     ri = pow(R64, -1, R.P)

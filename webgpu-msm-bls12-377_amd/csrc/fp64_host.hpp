@@ -307,6 +307,8 @@ inline void teh_to_wire(const TeH::Ext& p, uint8_t out[96]) {
   Fp64::to_wire(y, out + 48);
 }
 // Same Horner as g1h_combine over Edwards partial records.
+inline bool teh_is_identity(const TeH::Ext& p) { return Fp64::is_zero(p.x) && Fp64::is_zero(Fp64::sub(p.y, p.z)); }
+inline TeH::Ext teh_add_skip_identity(const TeH::Ext& acc, const TeH::Ext& p) { return teh_is_identity(p) ? acc : TeH::add(acc, p); }
 inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
   TeH::Ext acc = TeH::identity();
   for (int b = 16 * num_windows - 1; b >= 0; b--) {
@@ -314,12 +316,54 @@ inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, uint32_t s
     const int w = b >> 4, l = b & 15;
     if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
-    if (l < 15) acc = TeH::add(acc, teh_from_record_words(base + (size_t)(1 + l) * 48));
-    if (l == 0) acc = TeH::add(acc, teh_from_record_words(base));
+    // identity points cost nothing: the records of a rank that folded its windows (g1_fold_tagged) are mostly that
+    if (l < 15) acc = teh_add_skip_identity(acc, teh_from_record_words(base + (size_t)(1 + l) * 48));
+    if (l == 0) acc = teh_add_skip_identity(acc, teh_from_record_words(base));
   }
   return acc;
 }
 inline void teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) { teh_to_wire(teh_horner(partials, num_windows), out); }
+
+inline void words_from_fp64(const Fp64::El& a, uint32_t* w12) {
+  for (int i = 0; i < 6; i++) {
+    w12[2 * i] = (uint32_t)a.v[i];
+    w12[2 * i + 1] = (uint32_t)(a.v[i] >> 32);
+  }
+}
+// A rank's own share of the host tail, before the exchange: the records of `count` CONSECUTIVE windows are replaced
+// by records with the same total -- point 0 of the first one becomes sum_w 2^(16 (w - first)) G_w (one short Horner
+// chain), every other point the identity -- so that the final combine, which skips identity points, is left with
+// its doublings and one addition per rank.  Records of mixed kinds are left as they are.
+inline void g1_fold_tagged(uint32_t* partials, int count) {
+  if (count <= 0) return;
+  const bool te = window_record_is_te(partials);
+  for (int w = 1; w < count; w++)
+    if (window_record_is_te(partials + (size_t)w * 16 * 48) != te) return;
+  uint32_t folded[48];
+  if (te) {
+    const TeH::Ext f = teh_horner(partials, count);
+    words_from_fp64(f.x, folded);
+    words_from_fp64(f.y, folded + 12);
+    words_from_fp64(f.t, folded + 24);
+    words_from_fp64(f.z, folded + 36);
+  } else {
+    const G1H::XYZZ f = g1h_horner(partials, count);
+    words_from_fp64(f.x, folded);
+    words_from_fp64(f.y, folded + 12);
+    words_from_fp64(f.zz, folded + 24);
+    words_from_fp64(f.zzz, folded + 36);
+  }
+  uint32_t ident[48];
+  memset(ident, 0, sizeof(ident));
+  uint32_t one[12];
+  words_from_fp64(Fp64::one(), one);
+  memcpy(ident + 12, one, sizeof(one));          // Y = 1 in both systems
+  if (te) memcpy(ident + 36, one, sizeof(one));  // Edwards identity (0, 1, 0, 1); Weierstrass: ZZ = ZZZ = 0
+  for (int k = 0; k < count * 16; k++) memcpy(partials + (size_t)k * 48, ident, sizeof(ident));
+  memcpy(partials, folded, sizeof(folded));
+  if (te)
+    for (int w = 0; w < count; w++) partials[(size_t)w * 16 * 48 + 11] |= TE_RECORD_TAG;
+}
 
 // Partial records of either kind, window by window (see TE_RECORD_TAG).  All of one kind: one Horner chain.  Mixed
 // (some ranks of a sharded MSM fell back to the Weierstrass path): one chain per kind over its own windows, the

@@ -48,7 +48,7 @@ constexpr uint32_t RP = NBIN + 1;  // row_ptr entries per window
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
 constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) blocks of the partition pass
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
-constexpr uint32_t SEG_MIN = 32;           // entries per accumulation work item (one thread), see auto_seg(); the work-item and overflow buffers are sized for SEG_MIN
+constexpr uint32_t SEG_MIN = 16;           // entries per accumulation work item (one thread), see auto_seg(); the work-item and overflow buffers are sized for SEG_MIN
 constexpr uint32_t SEG_MAX = 128;
 constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by length 0..seg
 constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2, ERR_TE_EXCEPTIONAL = 4;  // bits of the device error word
@@ -1215,7 +1215,10 @@ struct msm377_ctx {
   bool last_is_g1 = false;
   bool capture = false;
   bool timing = false;
-  uint32_t coop_from = 7;  // first reduction level run with one addition per lane quad (MSM377_COOP_FROM; 15 = never): measured 18-24 -> 13-18 us per level from level 7 on, slower before
+  // First reduction level run with one addition per lane quad.  0 = automatic: the first level whose 4 lanes x additions
+  // x windows fit one wave per SIMD (65536 lanes) -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from
+  // there on, slower before), 6 for 8, 4 for the 2 windows a rank of an 8-GPU run owns.  MSM377_COOP_FROM forces it (15 = never).
+  uint32_t coop_from = 0;
   // GLV front end of the Weierstrass path: 0 = off (default), 1 = on.  phi(P) = [lambda] P holds only for points of
   // the prime-order subgroup, so it is an opt-in: the caller vouches for the inputs (every protocol use does).
   // Interleaved A/B on one MI355X (tools/ab_knobs.py), Weierstrass plain vs GLV ms per MSM: 2^18 1.39 / 1.24,
@@ -1459,11 +1462,15 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       HIP_TRY(ctx, hipGetLastError());
       first_level = 3;
     }
+    uint32_t coop_from = ctx->coop_from;
+    if (coop_from == 0)
+      for (coop_from = 1; coop_from < TREE_LEVELS && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > 65536; coop_from++) {
+      }
     for (uint32_t r = first_level; r < TREE_LEVELS; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       bool done = false;
       if constexpr (CV::HAS_QUAD) {
-        if (r >= ctx->coop_from) {
+        if (r >= coop_from) {
           hipLaunchKernelGGL(k_tree_step_quad<CV>, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, buckets, r, ops, d_err);
           done = true;
         }
@@ -2055,6 +2062,12 @@ int msm377_g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, 
 int msm377_g1_combine_window_partials(const uint8_t* partials, uint32_t num_windows, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3) || num_windows == 0 || num_windows > MSM377_NUM_WINDOWS) return MSM377_EINVAL;
   g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), (int)num_windows, out_xy);
+  return MSM377_OK;
+}
+
+int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count) {
+  if (!partials || ((uintptr_t)partials & 3) || win_count > MSM377_NUM_WINDOWS) return MSM377_EINVAL;
+  g1_fold_tagged(reinterpret_cast<uint32_t*>(partials), (int)win_count);
   return MSM377_OK;
 }
 

@@ -89,6 +89,7 @@ def load_library():
         "msm377_ctx_set_stage_capture": (i32, [vp, i32]),
         "msm377_g1_read_stage": (i32, [vp, u32, vp, vp, vp, vp]),
         "msm377_g1_xyzz_to_affine": (i32, [vp, vp]),
+        "msm377_g1_fold_window_partials": (i32, [vp, ctypes.c_uint32]),
         "msm377_ctx_set_glv": (i32, [vp, i32]),
         "msm377_ctx_set_g1_form": (i32, [vp, i32]),
         "msm377_ctx_set_timing": (i32, [vp, i32]),
@@ -121,6 +122,22 @@ def combine_partials_bytes(partials: bytes, num_windows: int = NUM_WINDOWS) -> b
     if rc:
         raise MsmError(rc, "msm377_g1_combine_window_partials")
     return out.raw
+
+
+def fold_partials_bytes(partials: bytes) -> bytes:
+    """A rank's share of the host tail before the exchange (msm377_g1_fold_window_partials): the records of its
+    consecutive windows are replaced by records of the same size and total, all identity but one point."""
+    if len(partials) % WINDOW_PARTIAL_BYTES:
+        raise ValueError("partials must be whole window records")
+    count = len(partials) // WINDOW_PARTIAL_BYTES
+    if count == 0:
+        return partials
+    lib = load_library()
+    buf = (ctypes.c_uint32 * (len(partials) // 4)).from_buffer_copy(partials)
+    rc = lib.msm377_g1_fold_window_partials(ctypes.addressof(buf), count)
+    if rc:
+        raise MsmError(rc, "msm377_g1_fold_window_partials")
+    return bytes(buf)
 
 
 def xyzz_to_affine(words: Sequence[int]) -> bytes:

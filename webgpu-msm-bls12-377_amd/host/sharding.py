@@ -10,7 +10,7 @@ rank (msm377_g1_combine_partials).
 """
 from typing import Callable, Optional, Tuple
 
-from .engine import GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, combine_partials_bytes
+from .engine import GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, combine_partials_bytes, fold_partials_bytes
 
 
 def windows_for_rank(rank: int, world_size: int, num_windows: int = NUM_WINDOWS) -> Tuple[int, int]:
@@ -57,6 +57,10 @@ class ShardedMsm:
             return combine_partials_bytes(mine, self.num_windows)
         import torch.distributed as dist
 
+        # This rank's share of the host tail: fold its own windows into one point before the exchange, so that the
+        # combine every rank runs afterwards is doublings plus one addition per rank (the tail does not shrink
+        # with the number of GPUs otherwise).
+        mine = fold_partials_bytes(mine)
         if self.count:
             self.send_host.numpy()[: len(mine)] = memoryview(mine)
         self.send_dev.copy_(self.send_host, non_blocking=True)
@@ -91,6 +95,7 @@ def sharded_msm(
     import torch
     import torch.distributed as dist
 
+    mine = fold_partials_bytes(mine)  # this rank's share of the host tail, see ShardedMsm.run
     max_count = (NUM_WINDOWS + world_size - 1) // world_size
     slot = max_count * WINDOW_PARTIAL_BYTES
     send = torch.zeros(slot, dtype=torch.uint8)
