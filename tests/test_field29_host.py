@@ -20,7 +20,7 @@ SHIM_SO = os.path.join(ROOT, "tests", "native", "_build", "libfield29_shim.so")
 
 @pytest.fixture(scope="module")
 def shim():
-    deps = [SHIM_SRC] + [os.path.join(CSRC, f) for f in ("field29.hpp", "g1_xyzz.hpp", "fp64_host.hpp", "consts_gen.hpp")]
+    deps = [SHIM_SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     if not os.path.exists(SHIM_SO) or any(os.path.getmtime(d) > os.path.getmtime(SHIM_SO) for d in deps):
         os.makedirs(os.path.dirname(SHIM_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I", CSRC, "-o", SHIM_SO, SHIM_SRC])
