@@ -5,6 +5,7 @@ import ctypes
 import os
 import random
 import struct
+import sys
 import subprocess
 
 import pytest
@@ -200,6 +201,14 @@ def test_twisted_edwards_exceptional_inputs_are_flagged(shim):
     out = ctypes.create_string_buffer(96)
     ext = (ctypes.c_uint32 * 52)()
     assert shim.shim_te_sum(xy24(two_torsion), (ctypes.c_uint8 * 1)(0), 1, 1, 0, out, ext) == 1
+    te = util.te_params()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_consts
+
+    x4 = (-1 - pow(te["s"], -1, R.P)) % R.P  # the order-4 point with s (x + 1) = -1
+    t4 = (x4, gen_consts._sqrt_p((x4 ** 3 + 1) % R.P))
+    assert R.add(t4, t4) == two_torsion
+    assert shim.shim_te_sum(xy24(t4), (ctypes.c_uint8 * 1)(0), 1, 1, 0, out, ext) == 1
     # Q = P + T2 for a subgroup point P: P - Q = T2 is exceptional for the Edwards law
     p = R.mul(R.G, 12345)
     qpt = R.add(p, two_torsion)

@@ -10,6 +10,8 @@ import ctypes
 import random
 
 import numpy as np
+import os
+
 import pytest
 
 import pyref as R
@@ -228,7 +230,14 @@ def test_points_outside_the_prime_order_subgroup(engine, oracle):
     shifted = [R.add(p, t2) for p in rnd_pts[:10]]
     for a in shifted:
         assert (a[1] * a[1] - a[0] ** 3 - 1) % R.P == 0
+    te = util.te_params()
+    x4 = (-1 - pow(te["s"], -1, R.P)) % R.P  # s (x + 1) = -1: the order-4 point over (-1, 0), where u + 1 = 0
+    import gen_consts  # tools/ (put on sys.path by util.te_params)
+
+    t4 = (x4, gen_consts._sqrt_p((x4 ** 3 + 1) % R.P))
+    assert R.add(t4, t4) == t2
     cases = {
+        "order-4 input": rnd_pts[:3] + [t4] + rnd_pts[3:6] + [R.neg(t4)],
         "two-torsion input": rnd_pts[:5] + [t2] + rnd_pts[5:9],
         "P and P + T2 in one bucket": [rnd_pts[0], shifted[0]] + rnd_pts[1:4],
         "cofactor points only": shifted,
