@@ -350,6 +350,32 @@ def test_window_sharding_on_one_gpu(engine, oracle, world):
     assert msm.combine_partials(b"".join(parts)) == util.oracle_msm(oracle, pts, ks)
 
 
+def test_host_buffers_upload_in_two_chunks(oracle, monkeypatch):
+    """msm377_g1_msm with large host buffers uploads and accumulates in two chunks of points (chunk B on top of chunk
+    A's buckets, one reduction): forced here at small sizes through MSM377_UPLOAD_CHUNK_MIN; both coordinate forms,
+    ragged sizes, skew, and an exceptional point in the second chunk (whole call reruns on the Weierstrass path)."""
+    monkeypatch.setenv("MSM377_UPLOAD_CHUNK_MIN", "100")
+    eng = msm.MsmEngine(1 << 17)
+    try:
+        for n in (128, 131, 1000, 4097, 70001):
+            pts, ks = seeded_inputs(oracle, n, 600 + n)
+            exp = util.oracle_msm(oracle, pts, ks)
+            for form in ("edwards", "weierstrass"):
+                eng.set_g1_form(form)
+                assert eng.msm(pts, ks) == exp, (n, form)
+            eng.set_g1_form("edwards")
+        n = 3000
+        pts, _ = seeded_inputs(oracle, n, 77)
+        ks = R.encode_scalars([R.rand_scalars(5, 1)[0]] * n)  # one bucket per window, split rows in both chunks
+        assert eng.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+        pl = R.decode_points(pts)[:400]
+        pl[333] = (R.P - 1, 0)
+        kl = R.rand_scalars(9, 400)
+        assert eng.msm(R.encode_points(pl), R.encode_scalars(kl)) == R.encode_result(R.msm_naive(pl, kl))
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_window_sharding_with_mixed_record_forms(engine, oracle, world):
     """Partial records carry their coordinate system (twisted Edwards by default, Weierstrass after a fallback or

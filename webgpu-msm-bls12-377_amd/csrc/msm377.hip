@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
                                                        const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                       int* __restrict__ err, const int* __restrict__ conv_err) {
+                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into) {
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v == 0 && *conv_err) atomicOr(err, *conv_err);  // the table holds a point its coordinate system cannot represent
   if (v >= *work_total) return;
@@ -825,7 +825,9 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   const uint32_t seglen = row_split(row_end - row_beg, SEG).seglen;
   uint32_t k = row_beg + it.seg * seglen;
   const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
-  typename CV::Pt acc = CV::identity();
+  // into: the buckets already hold the sums of an earlier chunk of the same MSM (host-buffer entry point, chunked
+  // upload): the row's first item continues from there.
+  typename CV::Pt acc = (into && it.seg == 0) ? load_bucket<CV>(buckets, ws, t) : CV::identity();
   bool bad = false;  // an exceptional pair of the twisted Edwards law (te377.hpp): sticky, the caller falls back
   if (k < end) {
     // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
@@ -1303,6 +1305,8 @@ struct msm377_ctx {
   hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
   hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
   hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
+  uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
+  std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   TailPool tail_pool;
   int tail_threads = 4;               // MSM377_TAIL_THREADS=1: single-threaded host tail
   int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
@@ -1322,15 +1326,15 @@ bool hip_ok(msm377_ctx* ctx, hipError_t e, const char* what) {
     if (!hip_ok((ctx), (call), #call)) return MSM377_EHIP; \
   } while (0)
 
-// Pageable host memory -> device through a pinned staging buffer: four workers copy 8 MB chunks
-// into it and queue the DMA of each chunk on their own stream, so the CPU copy of one chunk
+// Pageable host memory -> device through a pinned staging buffer: four workers copy ~4 MB pieces
+// into it and queue the DMA of each piece on their own stream, so the CPU copy of one piece
 // overlaps the DMA of the others.  Measured on the MI355X box for 160 MB: 4.2 ms, against 28 ms
 // for a first hipMemcpy from fresh pageable pages (4.4 ms once the runtime has pinned them) and
 // 3.3 + 2.9 ms for hipHostRegister + copy.  Returns when the data is on the device.
 int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, size_t stage_off) {
   constexpr int NT = 4;
-  constexpr size_t CHUNK = 8u << 20;
-  if (bytes < CHUNK) {  // not worth four threads
+  constexpr size_t SMALL = 8u << 20, PIECE = 4u << 20;
+  if (bytes < SMALL) {  // not worth four threads
     HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return MSM377_OK;
   }
@@ -1342,7 +1346,12 @@ int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, s
     }
     for (int t = 0; t < NT; t++) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
   }
-  const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+  // Pieces of about 4 MB, their number a multiple of the worker count: every worker copies the same amount (with
+  // fixed 8 MB pieces a 48 MB upload took as long as a 64 MB one), and a worker's host copy of piece k+1 overlaps
+  // the DMA of piece k.
+  size_t npieces = (bytes + PIECE - 1) / PIECE;
+  npieces = (npieces + NT - 1) / NT * NT;
+  const size_t piece = ((bytes + npieces - 1) / npieces + 4095) & ~(size_t)4095;
   uint8_t* stage = ctx->h_stage + stage_off;
   hipError_t errs[NT];
   std::thread workers[NT];
@@ -1351,8 +1360,10 @@ int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, s
     errs[t] = hipSuccess;
     workers[t] = std::thread([=, &errs] {
       hipError_t e = hipSetDevice(device);
-      for (size_t c = t; c < nchunks && e == hipSuccess; c += NT) {
-        const size_t off = c * CHUNK, len = (bytes - off < CHUNK) ? bytes - off : CHUNK;
+      for (size_t c = t; c < npieces && e == hipSuccess; c += NT) {
+        const size_t off = c * piece;
+        if (off >= bytes) break;
+        const size_t len = (bytes - off < piece) ? bytes - off : piece;
         memcpy(stage + off, src + off, len);
         e = hipMemcpyAsync((uint8_t*)d_dst + off, stage + off, len, hipMemcpyHostToDevice, ctx->copy_stream[t]);
       }
@@ -1384,15 +1395,16 @@ struct StageTimer {  // HIP events around one stage of one part, on the part's o
 };
 
 template <class CV>
-int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
+int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, uint64_t first = 0, bool clear_err = true) {
   // Runs on the side stream: it depends on the points only, while decomposition and the sort
   // depend on the scalars only, so the two overlap (HBM-bound vs LDS/latency-bound);
   // k_accumulate waits for `bases_ready`.  Every entry point ends with a host-side wait for the
   // main stream, so the previous call's readers of d_bases are done.
   if (n == 0) return MSM377_OK;
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
-  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n, ctx->d_err + 2);
+  if (clear_err) HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
+  hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases + first * CV::REC_WORDS, n,
+                     ctx->d_err + 2);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
@@ -1422,6 +1434,15 @@ constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POI
 // Nothing here waits for the GPU.
 // One part of a call's windows: window slots [ws0, ws0 + wc) of every window-indexed buffer, windows
 // [wb, wb + wc) of the scalars, on its own stream.
+// Which stages of a call to enqueue (all of them, except for the chunked host-buffer entry point).
+struct Phase {
+  bool clear_err = true;   // first chunk of a call
+  bool front = true;       // decompose .. merge
+  bool into = false;       // accumulate on top of the buckets of an earlier chunk
+  bool back = true;        // bucket reduction, gather, D2H, completion event
+  uint64_t base_first = 0; // first record of ctx->d_bases this chunk's indices refer to
+};
+
 struct PartView {
   hipStream_t st;
   uint32_t part, ws0, wb, wc;
@@ -1430,7 +1451,7 @@ struct PartView {
 
 template <class CV, class BP>
 int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint64_t n, const PartView& pv, int* d_err, uint32_t* d_partials, bool glv,
-                 uint32_t sort_blocks) {
+                 uint32_t sort_blocks, const Phase& ph) {
   hipStream_t st = pv.st;
   const uint32_t wc = pv.wc, part = pv.part;
   const uint32_t SEG = auto_seg(ctx, (uint64_t)wc * n, glv);  // per launch: each part must fill the GPU on its own
@@ -1445,6 +1466,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   uint32_t* split_rows = ctx->d_split_rows + (size_t)pv.ws0 * NB;
   WorkItem* work = ctx->d_work + pv.work_off;
   uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::PT_WORDS;
+  const uint32_t* bases = ctx->d_bases + ph.base_first * BP::REC_WORDS;
+  if (ph.front) {
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (glv)
@@ -1485,6 +1508,12 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, row_ptr, rows, SEG, cursor, work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
+    if (ctx->before_accumulate) {  // must run before the wait below is queued: the wait binds to the event's latest record
+      std::function<int()> f;
+      f.swap(ctx->before_accumulate);
+      const int hook_rc = f();
+      if (hook_rc) return hook_rc;
+    }
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->bases_ready, 0));
     // The accumulation launches of the two parts run one after the other (the second waits for the first): they
     // are the power-limited kernels, sharing the GPU would only stretch both.
@@ -1493,17 +1522,17 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL, st, part);
       const dim3 grid((unsigned)((max_items + 255) / 256));
       if constexpr (!std::is_same<BP, CV>::value)
-        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2, ph.into ? 1u : 0u);
       else if (ctx->acc_occ == 4)
-        hipLaunchKernelGGL((k_accumulate<CV, 4>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 4>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2, ph.into ? 1u : 0u);
       else if (ctx->acc_occ == 3)
-        hipLaunchKernelGGL((k_accumulate<CV, 3>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 3>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2, ph.into ? 1u : 0u);
       else
-        hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, ctx->d_bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2);
+        hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2, ph.into ? 1u : 0u);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
@@ -1520,6 +1549,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
                          row_ovf_base, ovf, SEG, d_err);
     HIP_TRY(ctx, hipGetLastError());
   }
+  }  // ph.front
+  if (!ph.back) return MSM377_OK;
   if (ctx->capture) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, buckets, (size_t)wc * CV::PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
   }
@@ -1563,14 +1594,16 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
 // bound), and part 0's merge and bucket reduction (short launches, latency bound from level 5 on) overlap
 // part 1's accumulation.  Only the second part's reduction stays exposed.
 template <class CV, class BP = CV>
-int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false) {
+int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false,
+                    const Phase& ph = Phase()) {
   // GLV front end: n_scalars scalars become 2 n_scalars (point, half-scalar) columns over 8 windows.
   const uint64_t n = glv ? 2 * n_scalars : n_scalars;
   hipStream_t st = ctx->stream;
   int* d_err = ctx->d_err + slot;
   uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
-  const uint32_t parts = (ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
-  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
+  const bool whole = ph.front && ph.back;  // the two-stream pipeline only for calls enqueued in one piece
+  const uint32_t parts = (whole && ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
+  if (ph.clear_err) HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
   PartView pv[2];
   const uint32_t wc0 = parts == 2 ? (wc + 1) / 2 : wc;
   pv[0] = PartView{st, 0, 0, wb, wc0, 0, 0};
@@ -1581,9 +1614,10 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   }
   ctx->last_parts = parts;
   for (uint32_t p = 0; p < parts; p++) {
-    int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS);
+    int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS, ph);
     if (rc) return rc;
   }
+  if (!ph.back) return MSM377_OK;
   if (parts == 2) {
     HIP_TRY(ctx, hipEventRecord(ctx->part_join, ctx->stream3));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->part_join, 0));
@@ -1806,6 +1840,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
@@ -1925,10 +1960,85 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
     return MSM377_OK;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 96, 0);
-  if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
+  ctx->bases_n = 0;
+  int form = pick_form(ctx, n);
+  const uint32_t* d_sc = ctx->d_raw_scalars;
+  const uint32_t* d_pt = ctx->d_raw_points;
+  int rc;
+  if (n >= ctx->upload_chunk_min && form != TABLE_XYZZ_GLV) {
+    // Large inputs in host memory: the upload (3.3 ms for 2^20 points from pageable memory) is as long as the whole
+    // computation, so the MSM runs as TWO chunks of points: chunk A's decompose .. accumulate .. merge runs while
+    // chunk B is on its way, chunk B accumulates on top of A's buckets (Phase::into), and reduction and tail run once.
+    const uint64_t nA = std::max<uint64_t>(64, (n / 2) & ~63ull), nB = n - nA;
+    const size_t sc_stage = (size_t)ctx->cap * 96;
+    rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, nA * 32, sc_stage);
+    if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_points, points, nA * 96, 0);
+    if (rc) return rc;
+    int up_rc = MSM377_OK;
+    std::thread upload([&] {
+      if (hipSetDevice(ctx->device) != hipSuccess) {
+        up_rc = MSM377_EHIP;
+        return;
+      }
+      up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + nA * 32, scalars + nA * 32, nB * 32, sc_stage + nA * 32);
+      if (up_rc == MSM377_OK) up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + nA * 96, points + nA * 96, nB * 96, nA * 96);
+    });
+    const bool te = form == TABLE_TE;
+    Phase pa, pb;
+    pa.back = false;
+    pb.clear_err = false;
+    pb.into = true;
+    pb.base_first = nA;
+    rc = te ? convert_bases<TeDev>(ctx, d_pt, nA) : convert_bases<G1Dev>(ctx, d_pt, nA);
+    if (rc == MSM377_OK)
+      rc = te ? enqueue_windows<TeDev>(ctx, d_sc, nA, 0, MSM377_NUM_WINDOWS, 0, false, pa) : enqueue_windows<G1Dev>(ctx, d_sc, nA, 0, MSM377_NUM_WINDOWS, 0, false, pa);
+    upload.join();
+    if (rc == MSM377_OK) rc = up_rc;
+    if (rc == MSM377_OK) rc = te ? convert_bases<TeDev>(ctx, d_pt + nA * 24, nB, nA, false) : convert_bases<G1Dev>(ctx, d_pt + nA * 24, nB, nA, false);
+    if (rc == MSM377_OK)
+      rc = te ? enqueue_windows<TeDev>(ctx, d_sc + nA * 8, nB, 0, MSM377_NUM_WINDOWS, 0, false, pb)
+              : enqueue_windows<G1Dev>(ctx, d_sc + nA * 8, nB, 0, MSM377_NUM_WINDOWS, 0, false, pb);
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    if (!(te && (ctx->h_err[0] & ERR_TE_EXCEPTIONAL))) {
+      rc = finish_windows(ctx, 0);
+      if (rc) return rc;
+      auto t0 = std::chrono::steady_clock::now();
+      if (te)
+        te_tail(ctx, ctx->h_partials, out_xy);
+      else
+        xyzz_tail(ctx, ctx->h_partials, out_xy);
+      time_tail(ctx, t0);
+      return MSM377_OK;
+    }
+    // exceptional case of the Edwards law: everything is on the device by now, rerun in one piece below
+  } else {
+    // Scalars first: decomposition, sort and the work lists need nothing else, so they run while the points (three
+    // quarters of the bytes) are still on their way; the conversion is launched when the upload lands, right before
+    // the accumulation is queued.
+    rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
+    if (rc) return rc;
+    int up_rc = MSM377_OK;
+    std::thread upload([&] {
+      up_rc = hipSetDevice(ctx->device) == hipSuccess ? h2d_staged(ctx, ctx->d_raw_points, points, n * 96, 0) : MSM377_EHIP;
+    });
+    ctx->before_accumulate = [&]() -> int {
+      if (upload.joinable()) upload.join();
+      if (up_rc) return up_rc;
+      return convert_table(ctx, d_pt, n, form);
+    };
+    rc = g1_table_msm(ctx, d_sc, n, form, out_xy);
+    ctx->before_accumulate = nullptr;
+    if (upload.joinable()) upload.join();  // an error before the hook ran
+    if (rc != RC_TE_FALLBACK) return rc;
+  }
+  form = TABLE_XYZZ;
+  rc = convert_table(ctx, d_pt, n, form);
   if (rc) return rc;
-  return msm377_g1_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
+  return g1_table_msm(ctx, d_sc, n, form, out_xy);
 }
 
 // ---- Edwards-BLS12 (BASELINE.json config 3): same pipeline, EdDev policy ----
