@@ -1,3 +1,4 @@
+"""Interleaved timing of msm377_g1_msm (host buffers, upload included) with different chunk splits, one process."""
 import os, sys, time, statistics
 sys.path.insert(0, os.getcwd())
 import torch
@@ -7,10 +8,11 @@ n = 1 << 20
 d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
 scal = bench.seeded_scalars(0x5CA1A5, n)
 engs = {}
-for name, v in (("chunked", "262144"), ("whole", "99999999999")):
+for name, v, split in (("chunked 55", "262144", "55"), ("chunked 60", "262144", "60"), ("chunked 65", "262144", "65"), ("chunked 70", "262144", "70"), ("whole", "99999999999", "50")):
     os.environ["MSM377_UPLOAD_CHUNK_MIN"] = v
+    os.environ["MSM377_UPLOAD_SPLIT"] = split
     engs[name] = msm.MsmEngine(n, device=0)
-engs["chunked"].generate_bases_device(0x377, n, d_points.data_ptr())
+engs["whole"].generate_bases_device(0x377, n, d_points.data_ptr())
 pts = d_points.cpu().numpy().tobytes()
 ref = None
 for name, e in engs.items():

@@ -1306,6 +1306,7 @@ struct msm377_ctx {
   hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
   hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
+  uint32_t upload_split_pct = 55;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 10..90)
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   TailPool tail_pool;
   int tail_threads = 4;               // MSM377_TAIL_THREADS=1: single-threaded host tail
@@ -1840,6 +1841,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 10), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
@@ -1969,7 +1971,7 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
     // Large inputs in host memory: the upload (3.3 ms for 2^20 points from pageable memory) is as long as the whole
     // computation, so the MSM runs as TWO chunks of points: chunk A's decompose .. accumulate .. merge runs while
     // chunk B is on its way, chunk B accumulates on top of A's buckets (Phase::into), and reduction and tail run once.
-    const uint64_t nA = std::max<uint64_t>(64, (n / 2) & ~63ull), nB = n - nA;
+    const uint64_t nA = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull), nB = n - nA;
     const size_t sc_stage = (size_t)ctx->cap * 96;
     rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, nA * 32, sc_stage);
     if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_points, points, nA * 96, 0);
