@@ -11,10 +11,15 @@
 //   k_accumulate      bucket sums (the dominant kernel)          wgsl/cuzk/smvp_bls12_377.template.wgsl:72-160
 //   k_tree_step       bucket reduction, log-depth bit planes     wgsl/cuzk/bpr.template.wgsl:69-173; models cuzk/bpr.ts:5-126
 //   host tail         Horner over windows + one inversion        submission.ts:290-321
+// The kernels are templates over a curve policy: TeDev (default: G1 in twisted Edwards form, te377.hpp -- 8 field
+// products per bucket addition, unified law, exceptional cases detected and rerun), G1Dev (G1 in Weierstrass XYZZ
+// coordinates, g1_xyzz.hpp: the fallback, the GLV front end, the stage read-backs) and EdDev (Edwards-BLS12 over
+// the scalar field, ed_ext.hpp).
 //
 // HBM layout (n points, W window slots, NB = 32768 buckets per window):
-//   bases    n x 128 B records: x[13] y[13] pad[6] u32 (29-bit limbs, Montgomery R = 2^377);
-//            one record = one 128-byte line, so a gather touches exactly one line
+//   bases    TeDev: n x 256 B records (Y-X)[13] (Y+X)[13] (2dT)[13] (2Z)[13] pad[12] u32; G1Dev: n x 128 B
+//            x[13] y[13] pad[6] (29-bit limbs, Montgomery R = 2^406); records are line-aligned, so a gather
+//            touches exactly two (one) 128-byte lines
 //   digits   W x n u16, window-major: biased digit d + 2^15 (the reference's chunks[] as u32)
 //   row_ptr  W x 32770 u32: CSR offsets over keys |d| in 0..32768 (the reference keeps 65537
 //            signed rows; here +t and -t share row t and the sign rides in val_idx bit 31)
@@ -27,14 +32,14 @@
 #include <string.h>
 
 #include <algorithm>
-#include <type_traits>
 #include <atomic>
 #include <chrono>
-#include <functional>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/msm377.h"
