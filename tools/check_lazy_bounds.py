@@ -14,30 +14,39 @@ import os
 import re
 import sys
 
-P = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
-LB, N, RS = 29, 13, 14
+P_FP = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+Q_FQ = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+LB = 29
 BETA = 1 << LB
 MASK = BETA - 1
-E = 1 << 354
-MOD = [(P >> (LB * j)) & MASK for j in range(N)]
+# the field under test (use_field): modulus, limbs, reduction steps, slack of a lazy product above the modulus
+P, N, RS, E, MOD, K = None, None, None, None, None, None
 
 
-def load_consts():
+def load_consts(struct, end, n, rs):
     here = os.path.dirname(os.path.abspath(__file__))
     text = open(os.path.join(here, "..", "webgpu-msm-bls12-377_amd", "csrc", "consts_gen.hpp")).read()
-    g1 = text[text.index("struct G1Consts") : text.index("struct GlvConsts")]
+    body = text[text.index("struct " + struct) : text.index(end)]
     out = {}
     for name in ("KP2", "KP6", "KP4W3", "MOD", "MOD2", "MOD4"):
-        m = re.search(r"uint32_t %s\[13\] = \{([^}]*)\}" % name, g1)
+        m = re.search(r"uint32_t %s\[%d\] = \{([^}]*)\}" % (name, n), body)
         out[name] = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
-    assert "RS = 14" in g1
+    assert "RS = %d" % rs in body
     return out
 
 
-K = load_consts()
-assert K["MOD"] == MOD
-for name, k in (("KP2", 2), ("KP6", 6), ("KP4W3", 4), ("MOD2", 2), ("MOD4", 4)):
-    assert sum(x << (LB * j) for j, x in enumerate(K[name])) == k * P, name
+def use_field(which):
+    global P, N, RS, E, MOD, K
+    if which == "Fp":
+        P, N, RS, E = P_FP, 13, 14, 1 << 354
+        K = load_consts("G1Consts", "struct GlvConsts", N, RS)
+    else:  # Fq: R = 2^261 = 438 q; a lazy product of values below 5q exceeds q by less than q / 16
+        P, N, RS, E = Q_FQ, 9, 9, Q_FQ // 16
+        K = load_consts("EdConsts", "struct G1Consts64", N, RS)
+    MOD = [(P >> (LB * j)) & MASK for j in range(N)]
+    assert K["MOD"] == MOD
+    for name, k in (("KP2", 2), ("KP6", 6), ("KP4W3", 4), ("MOD2", 2), ("MOD4", 4)):
+        assert sum(x << (LB * j) for j, x in enumerate(K[name])) == k * P, name
 
 
 class V:
@@ -129,7 +138,7 @@ def add_lz(a, b, name):
 
 
 def norm(a, name):
-    assert a.hi < (1 << 380), (name, a.hi / P)
+    assert a.hi < (1 << (LB * (N - 1) + 32)), (name, a.hi / P)  # the top limb must fit 32 bits
     return nform(a.hi, a.lo, name)
 
 
@@ -156,7 +165,41 @@ def point_formula(x1, y1, zz1, zzz1, u_in, s_in, kp_p, kname_p, p_mults, tag):
     return x3, y3, pp, ppp, r, d, qq
 
 
+def te_formulas(canonical):
+    """te377.hpp TeLazy: every stored coordinate is a lazy product (M1), base records canonical."""
+
+    def te_finish(a, b, c, d, tag):
+        e = norm(add_kp_sub(b, "KP2", 2, a, tag + " E"), tag + " E")
+        f = norm(add_kp_sub(d, "KP2", 2, c, tag + " F"), tag + " F")
+        g = norm(add_lz(d, c, tag + " G"), tag + " G")
+        h = add_lz(b, a, tag + " H")
+        for nm, (x, y) in (("X3", (e, f)), ("Y3", (h, g)), ("T3", (h, e)), ("Z3", (f, g))):
+            mul_lz(x, y, "%s %s" % (tag, nm))
+
+    PX, PY, PT, PZ = m1("PX"), m1("PY"), m1("PT"), m1("PZ")
+    a = mul_lz(add_kp_sub(PY, "KP2", 2, PX, "te madd Y-X"), canonical, "te madd A")
+    b = mul_lz(add_lz(PY, PX, "te madd Y+X"), canonical, "te madd B")
+    c = mul_lz(kp_sub("KP2", 2, canonical, "te madd -kt"), PT, "te madd C")
+    d = mul_lz(PZ, canonical, "te madd D")
+    te_finish(a, b, c, d, "te madd")
+    a = mul_lz(norm(add_kp_sub(PY, "KP2", 2, PX, "te add Y1-X1"), "te add Y1-X1"), norm(add_kp_sub(PY, "KP2", 2, PX, "te add Y2-X2"), "te add Y2-X2"), "te add A")
+    b = mul_lz(norm(add_lz(PY, PX, "te add Y1+X1"), "te add Y1+X1"), norm(add_lz(PY, PX, "te add Y2+X2"), "te add Y2+X2"), "te add B")
+    c = mul_lz(mul_lz(PT, PT, "te add T1T2"), canonical, "te add C")
+    d = mul_lz(PZ, PZ, "te add D")
+    te_finish(a, b, c, add_lz(d, d, "te add 2D"), "te add")
+    # madd_affine: A, B, C as in madd, D = 2 Z1 limb-wise
+    a = mul_lz(add_kp_sub(PY, "KP2", 2, PX, "te amadd Y-X"), canonical, "te amadd A")
+    b = mul_lz(add_lz(PY, PX, "te amadd Y+X"), canonical, "te amadd B")
+    c = mul_lz(kp_sub("KP2", 2, canonical, "te amadd -kt"), PT, "te amadd C")
+    te_finish(a, b, c, add_lz(PZ, PZ, "te amadd 2Z"), "te amadd")
+    # canonical operations on stored (lazy) coordinates: mul() = reduce_once(mul_lz()) needs mul_lz < 2p
+    mul_lz(PX, canonical, "gather X*TO64")
+
+
 def main():
+    use_field("Fq")  # Edwards-BLS12 buckets (EdDev): same law over the 9-limb field
+    te_formulas(nform(P, 0, "canonical"))
+    use_field("Fp")
     canonical = nform(P, 0, "canonical")
     X1 = nform(5 * P + E, 0, "X1")
     Y1, ZZ1, ZZZ1 = m1("Y1"), m1("ZZ1"), m1("ZZZ1")
@@ -186,31 +229,7 @@ def main():
     y = norm(add_kp_sub(a, "KP2", 2, b, "quad Y3"), "quad Y3")
     canon_ok(y, "quad canon(Y3)")
 
-    # ---- te377.hpp: twisted Edwards form; every stored coordinate is a lazy product (M1), base records canonical ----
-    def te_finish(a, b, c, d, tag):
-        e = norm(add_kp_sub(b, "KP2", 2, a, tag + " E"), tag + " E")
-        f = norm(add_kp_sub(d, "KP2", 2, c, tag + " F"), tag + " F")
-        g = norm(add_lz(d, c, tag + " G"), tag + " G")
-        h = add_lz(b, a, tag + " H")
-        for nm, (x, y) in (("X3", (e, f)), ("Y3", (h, g)), ("T3", (h, e)), ("Z3", (f, g))):
-            mul_lz(x, y, "%s %s" % (tag, nm))
-
-    PX, PY, PT, PZ = m1("PX"), m1("PY"), m1("PT"), m1("PZ")
-    a = mul_lz(add_kp_sub(PY, "KP2", 2, PX, "te madd Y-X"), canonical, "te madd A")
-    b = mul_lz(add_lz(PY, PX, "te madd Y+X"), canonical, "te madd B")
-    c = mul_lz(kp_sub("KP2", 2, canonical, "te madd -kt"), PT, "te madd C")
-    d = mul_lz(PZ, canonical, "te madd D")
-    te_finish(a, b, c, d, "te madd")
-    a = mul_lz(norm(add_kp_sub(PY, "KP2", 2, PX, "te add Y1-X1"), "te add Y1-X1"), norm(add_kp_sub(PY, "KP2", 2, PX, "te add Y2-X2"), "te add Y2-X2"), "te add A")
-    b = mul_lz(norm(add_lz(PY, PX, "te add Y1+X1"), "te add Y1+X1"), norm(add_lz(PY, PX, "te add Y2+X2"), "te add Y2+X2"), "te add B")
-    c = mul_lz(mul_lz(PT, PT, "te add T1T2"), canonical, "te add C")
-    d = mul_lz(PZ, PZ, "te add D")
-    te_finish(a, b, c, add_lz(d, d, "te add 2D"), "te add")
-    # madd_affine: A, B, C as in madd, D = 2 Z1 limb-wise
-    a = mul_lz(add_kp_sub(PY, "KP2", 2, PX, "te amadd Y-X"), canonical, "te amadd A")
-    b = mul_lz(add_lz(PY, PX, "te amadd Y+X"), canonical, "te amadd B")
-    c = mul_lz(kp_sub("KP2", 2, canonical, "te amadd -kt"), PT, "te amadd C")
-    te_finish(a, b, c, add_lz(PZ, PZ, "te amadd 2Z"), "te amadd")
+    te_formulas(canonical)
 
     # canonical operations on stored (lazy) coordinates: mul() = reduce_once(mul_lz()) needs mul_lz < 2p
     mul_lz(X1, canonical, "gather X*TO64")

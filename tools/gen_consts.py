@@ -205,7 +205,8 @@ def main():
                 "TE_SBR": s_ * GLV_BETA * R29, "TE_CSBR": c_ * s_ * GLV_BETA * R29}
     s += emit("G1Consts", P, 13, g1_extra, rs=14, lazy=True)
     s += emit_glv()
-    s += emit("EdConsts", Q, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D, "GEN_X": ED_GX, "GEN_Y": ED_GY})
+    # Fq keeps R = 2^261 (9 steps): q is 253 bits, so the radix already leaves 8 bits of slack for the lazy forms
+    s += emit("EdConsts", Q, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D, "GEN_X": ED_GX, "GEN_Y": ED_GY, "TE_2D": 2 * ED_D}, lazy=True)
     s += emit64("G1Consts64", P, 6, 14, {"TE_2D": 2 * d_, "TE_INV_S": pow(s_, -1, P), "TE_C_OVER_S": c_ * pow(s_, -1, P)})
     s += emit64("EdConsts64", Q, 4, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D})
     s += "}  // namespace msm377\n"

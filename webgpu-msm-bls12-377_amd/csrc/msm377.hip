@@ -150,13 +150,13 @@ struct EdDev {
   using F = Fq;
   static constexpr uint32_t NL = 9, NW32 = 8;
   static __device__ __forceinline__ Fq::El to64() { return Fq::from_const(EdConsts::TO64); }
-  using Base = Ed::Base;
-  using Pt = Ed::Ext;
+  using Base = EdLazy::ABase;  // buckets and additions in the lazy forms (te377.hpp TeLazy); the law is complete
+  using Pt = EdLazy::Ext;
   // record: (y - x)[9] (y + x)[9] (2d x y)[9] pad[5]
   static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
     Fq::El x = Fq::to_mont(Fq::from_words<8>(raw));
     Fq::El y = Fq::to_mont(Fq::from_words<8>(raw + 8));
-    Base b = Ed::make_base(x, y);
+    const Ed::Base b = Ed::make_base(x, y);
 #pragma unroll
     for (int j = 0; j < 9; j++) {
       rec[j] = b.ymx.l[j];
@@ -181,9 +181,9 @@ struct EdDev {
   }
 
   static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // complete addition law
-  static __device__ __forceinline__ Pt identity() { return Ed::identity(); }
-  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Ed::madd(a, Ed::cneg(q, negq)); }
-  static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return Ed::add(a, b); }
+  static __device__ __forceinline__ Pt identity() { return EdLazy::identity(); }
+  static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return EdLazy::madd_affine(a, q, negq); }
+  static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return EdLazy::add(a, b); }
   static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
 #pragma unroll
     for (int j = 0; j < 9; j++) {

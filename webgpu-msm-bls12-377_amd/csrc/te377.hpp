@@ -34,21 +34,23 @@
 
 namespace msm377 {
 
-struct Te377 {
-  using F = Fp;
-  using El = Fp::El;
-  using K = G1Consts;
-
+// The lazy addition law itself, for any field with slack in its Montgomery radix and constants K (MOD, KP2, TE_2D):
+// Fp / G1Consts (this file's curve) and Fq / EdConsts (Edwards-BLS12, ed_ext.hpp -- R = 2^261 over a 253-bit q
+// already has the slack; its law is complete, is_bad never fires).
+template <class F_, class K_>
+struct TeLazy {
+  using F = F_;
+  using El = typename F::El;
+  using K = K_;
+  struct ABase {  // affine input point in precomputed form: y - x, y + x, 2d x y
+    El ymx, ypx, kt;
+  };
   struct PBase {  // projective input point in precomputed form, canonical coordinates
     El ymx, ypx, kt, z2;  // Y - X, Y + X, 2d T, 2 Z
-  };
-  struct ABase {  // affine input point in precomputed form (resident tables): y - x, y + x, 2d x y
-    El ymx, ypx, kt;
   };
   struct Ext {
     El x, y, t, z;
   };
-
   static MSM_HD Ext identity() {
     Ext r;
     r.x = F::zero();
@@ -57,6 +59,57 @@ struct Te377 {
     r.z = F::one();
     return r;
   }
+  // A stored coordinate (lazy product, carry-normalised) that is 0 mod p: all limbs zero, or exactly p.
+  static MSM_HD bool is_zero_mod_p(const El& a) { return F::is_zero(a) || F::eq(a, F::from_const(K::MOD)); }
+  static MSM_HD bool is_bad(const Ext& p) { return is_zero_mod_p(p.z); }
+
+  // p + q (neg: p - q; -(x, y) = (-x, y) swaps Y - X with Y + X and negates T): 8 products.
+  //   A, B, C, D lazy products (< p + e);  E = B - A + 2p, F = D - C + 2p  in (p - e, 3p + e),
+  //   G = D + C, H = B + A  < 2p + 2e;  E, F, G carry-normalised, H left limb-wise (limbs < 2^30).
+  static MSM_HD Ext madd(const Ext& p, const PBase& q, bool neg) {
+    const El a = F::mul_lz(F::add_kp_sub(p.y, K::KP2, p.x), F::select(neg, q.ypx, q.ymx));
+    const El b = F::mul_lz(F::add_lz(p.y, p.x), F::select(neg, q.ymx, q.ypx));
+    const El c = F::mul_lz(F::select(neg, F::kp_sub(K::KP2, q.kt), q.kt), p.t);
+    const El d = F::mul_lz(p.z, q.z2);
+    return finish(a, b, c, d);
+  }
+  // The same with an affine input point (Z2 = 1): 7 products; D = 2 Z1 limb-wise.
+  static MSM_HD Ext madd_affine(const Ext& p, const ABase& q, bool neg) {
+    const El a = F::mul_lz(F::add_kp_sub(p.y, K::KP2, p.x), F::select(neg, q.ypx, q.ymx));
+    const El b = F::mul_lz(F::add_lz(p.y, p.x), F::select(neg, q.ymx, q.ypx));
+    const El c = F::mul_lz(F::select(neg, F::kp_sub(K::KP2, q.kt), q.kt), p.t);
+    return finish(a, b, c, F::add_lz(p.z, p.z));
+  }
+  // General addition: 9 products (one of them by the constant 2d).
+  static MSM_HD Ext add(const Ext& p, const Ext& q) {
+    const El a = F::mul_lz(F::norm(F::add_kp_sub(p.y, K::KP2, p.x)), F::norm(F::add_kp_sub(q.y, K::KP2, q.x)));
+    const El b = F::mul_lz(F::norm(F::add_lz(p.y, p.x)), F::norm(F::add_lz(q.y, q.x)));
+    const El c = F::mul_lz(F::mul_lz(p.t, q.t), F::from_const(K::TE_2D));
+    const El d = F::mul_lz(p.z, q.z);
+    return finish(a, b, c, F::add_lz(d, d));
+  }
+  // E = B - A, F = D - C, G = D + C, H = B + A;  X3 = E F, Y3 = G H, T3 = E H, Z3 = F G.
+  // d may be limb-wise doubled (limbs < 2^30, value < 2p + 2e): F < 5p, G < 4p, still N-form after norm().
+  static MSM_HD Ext finish(const El& a, const El& b, const El& c, const El& d) {
+    const El e = F::norm(F::add_kp_sub(b, K::KP2, a));
+    const El f = F::norm(F::add_kp_sub(d, K::KP2, c));
+    const El g = F::norm(F::add_lz(d, c));
+    const El h = F::add_lz(b, a);
+    Ext r;
+    r.x = F::mul_lz(e, f);
+    r.y = F::mul_lz(h, g);
+    r.t = F::mul_lz(h, e);
+    r.z = F::mul_lz(f, g);
+    return r;
+  }
+};
+
+using EdLazy = TeLazy<Fq, EdConsts>;  // Edwards-BLS12 buckets (EdDev in msm377.hip)
+
+struct Te377 : TeLazy<Fp, G1Consts> {
+  using F = Fp;
+  using El = Fp::El;
+  using K = G1Consts;
 
   // Wire coordinates (12 little-endian u32 words each, canonical, NOT Montgomery) -> base record.  phi = true
   // converts the GLV image (beta x, y) of the same point.  b.z2 = 0 <=> the map is undefined at this point
@@ -97,52 +150,6 @@ struct Te377 {
     return b;
   }
 
-  // A stored coordinate (< p + 2^354, carry-normalised) that is 0 mod p: all limbs zero, or exactly p.
-  static MSM_HD bool is_zero_mod_p(const El& a) { return F::is_zero(a) || F::eq(a, F::from_const(K::MOD)); }
-  static MSM_HD bool is_bad(const Ext& p) { return is_zero_mod_p(p.z); }
-
-  // p + q (neg: p - q; -(x, y) = (-x, y) swaps Y - X with Y + X and negates T): 8 products.
-  //   A, B, C, D lazy products (< p + e);  E = B - A + 2p, F = D - C + 2p  in (p - e, 3p + e),
-  //   G = D + C, H = B + A  < 2p + 2e;  E, F, G carry-normalised, H left limb-wise (limbs < 2^30).
-  static MSM_HD Ext madd(const Ext& p, const PBase& q, bool neg) {
-    const El a = F::mul_lz(F::add_kp_sub(p.y, K::KP2, p.x), F::select(neg, q.ypx, q.ymx));
-    const El b = F::mul_lz(F::add_lz(p.y, p.x), F::select(neg, q.ymx, q.ypx));
-    const El c = F::mul_lz(F::select(neg, F::kp_sub(K::KP2, q.kt), q.kt), p.t);
-    const El d = F::mul_lz(p.z, q.z2);
-    return finish(a, b, c, d);
-  }
-
-  // The same with an affine input point (Z2 = 1): 7 products; D = 2 Z1 limb-wise.
-  static MSM_HD Ext madd_affine(const Ext& p, const ABase& q, bool neg) {
-    const El a = F::mul_lz(F::add_kp_sub(p.y, K::KP2, p.x), F::select(neg, q.ypx, q.ymx));
-    const El b = F::mul_lz(F::add_lz(p.y, p.x), F::select(neg, q.ymx, q.ypx));
-    const El c = F::mul_lz(F::select(neg, F::kp_sub(K::KP2, q.kt), q.kt), p.t);
-    return finish(a, b, c, F::add_lz(p.z, p.z));
-  }
-
-  // General addition: 9 products (one of them by the constant 2d).
-  static MSM_HD Ext add(const Ext& p, const Ext& q) {
-    const El a = F::mul_lz(F::norm(F::add_kp_sub(p.y, K::KP2, p.x)), F::norm(F::add_kp_sub(q.y, K::KP2, q.x)));
-    const El b = F::mul_lz(F::norm(F::add_lz(p.y, p.x)), F::norm(F::add_lz(q.y, q.x)));
-    const El c = F::mul_lz(F::mul_lz(p.t, q.t), F::from_const(K::TE_2D));
-    const El d = F::mul_lz(p.z, q.z);
-    return finish(a, b, c, F::add_lz(d, d));
-  }
-
-  // E = B - A, F = D - C, G = D + C, H = B + A;  X3 = E F, Y3 = G H, T3 = E H, Z3 = F G.
-  // d may be limb-wise doubled (limbs < 2^30, value < 2p + 2e): F < 5p, G < 4p, still N-form after norm().
-  static MSM_HD Ext finish(const El& a, const El& b, const El& c, const El& d) {
-    const El e = F::norm(F::add_kp_sub(b, K::KP2, a));
-    const El f = F::norm(F::add_kp_sub(d, K::KP2, c));
-    const El g = F::norm(F::add_lz(d, c));
-    const El h = F::add_lz(b, a);
-    Ext r;
-    r.x = F::mul_lz(e, f);
-    r.y = F::mul_lz(h, g);
-    r.t = F::mul_lz(h, e);
-    r.z = F::mul_lz(f, g);
-    return r;
-  }
 };
 
 }  // namespace msm377
