@@ -142,7 +142,7 @@ struct G1Dev {
 
 struct EdDev {
   static constexpr uint32_t REC_WORDS = 32;
-  static constexpr bool HAS_QUAD = false;
+  static constexpr bool HAS_QUAD = true;
   static constexpr bool IS_XYZZ = false;
   static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
   static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
@@ -974,18 +974,19 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
 // Broadcast lane K of every quad to its four lanes.  ds_bpermute (__shfl), not DPP quad_perm:
 // the DPP form produced wrong sums inside the looped merge kernel on ROCm 7.2 (the shuffle form
 // is bit-exact everywhere), and the crossbar cost is invisible next to a field multiplication.
-template <int K>
-__device__ __forceinline__ Fp::El quad_bcast(const Fp::El& v) {
-  Fp::El r;
+template <int K, int NLIMB>
+__device__ __forceinline__ Limbs<NLIMB> quad_bcast(const Limbs<NLIMB>& v) {
+  Limbs<NLIMB> r;
   const int src = (int)(((threadIdx.x & 63u) & ~3u) | (uint32_t)K);
 #pragma unroll
-  for (int j = 0; j < 13; j++) r.l[j] = (uint32_t)__shfl((int)v.l[j], src, 64);
+  for (int j = 0; j < NLIMB; j++) r.l[j] = (uint32_t)__shfl((int)v.l[j], src, 64);
   return r;
 }
-__device__ __forceinline__ Fp::El sel4(uint32_t q, const Fp::El& a0, const Fp::El& a1, const Fp::El& a2, const Fp::El& a3) {
-  Fp::El r;
+template <int NLIMB>
+__device__ __forceinline__ Limbs<NLIMB> sel4(uint32_t q, const Limbs<NLIMB>& a0, const Limbs<NLIMB>& a1, const Limbs<NLIMB>& a2, const Limbs<NLIMB>& a3) {
+  Limbs<NLIMB> r;
 #pragma unroll
-  for (int j = 0; j < 13; j++) {
+  for (int j = 0; j < NLIMB; j++) {
     const uint32_t lo = (q & 1) ? a1.l[j] : a0.l[j];
     const uint32_t hi = (q & 1) ? a3.l[j] : a2.l[j];
     r.l[j] = (q & 2) ? hi : lo;
@@ -1023,24 +1024,28 @@ __device__ __forceinline__ Fp::El coord4(uint32_t q, const G1XYZZ& p) { return s
 //   1: A = (Y1-X1)(Y2-X2) | B = (Y1+X1)(Y2+X2) | T1 T2 | Z1 Z2
 //   2: C = 2d (T1 T2)   (every lane: no exchange needed)
 //   3: X3 = E F | Y3 = H G | T3 = H E | Z3 = F G           -- the coordinate lane q stores
-__device__ __forceinline__ Te377::Ext add_quad(const Te377::Ext& a, const Te377::Ext& b, uint32_t q) {
-  using K = G1Consts;
-  const Fp::El m1 = Fp::mul_lz(sel4(q, Fp::norm(Fp::add_kp_sub(a.y, K::KP2, a.x)), Fp::norm(Fp::add_lz(a.y, a.x)), a.t, a.z),
-                               sel4(q, Fp::norm(Fp::add_kp_sub(b.y, K::KP2, b.x)), Fp::norm(Fp::add_lz(b.y, b.x)), b.t, b.z));
-  const Fp::El pa = quad_bcast<0>(m1), pb = quad_bcast<1>(m1), tt = quad_bcast<2>(m1), zz = quad_bcast<3>(m1);
-  const Fp::El c = Fp::mul_lz(tt, Fp::from_const(K::TE_2D));
-  const Fp::El d = Fp::add_lz(zz, zz);
-  const Fp::El e = Fp::norm(Fp::add_kp_sub(pb, K::KP2, pa)), f = Fp::norm(Fp::add_kp_sub(d, K::KP2, c));
-  const Fp::El g = Fp::norm(Fp::add_lz(d, c)), h = Fp::add_lz(pb, pa);
-  const Fp::El m3 = Fp::mul_lz(sel4(q, e, h, h, f), sel4(q, f, g, e, g));
-  Te377::Ext o;
+template <class F, class K>
+__device__ __forceinline__ typename TeLazy<F, K>::Ext te_add_quad(const typename TeLazy<F, K>::Ext& a, const typename TeLazy<F, K>::Ext& b, uint32_t q) {
+  using El = typename F::El;
+  const El m1 = F::mul_lz(sel4(q, F::norm(F::add_kp_sub(a.y, K::KP2, a.x)), F::norm(F::add_lz(a.y, a.x)), a.t, a.z),
+                          sel4(q, F::norm(F::add_kp_sub(b.y, K::KP2, b.x)), F::norm(F::add_lz(b.y, b.x)), b.t, b.z));
+  const El pa = quad_bcast<0>(m1), pb = quad_bcast<1>(m1), tt = quad_bcast<2>(m1), zz = quad_bcast<3>(m1);
+  const El c = F::mul_lz(tt, F::from_const(K::TE_2D));
+  const El d = F::add_lz(zz, zz);
+  const El e = F::norm(F::add_kp_sub(pb, K::KP2, pa)), f = F::norm(F::add_kp_sub(d, K::KP2, c));
+  const El g = F::norm(F::add_lz(d, c)), h = F::add_lz(pb, pa);
+  const El m3 = F::mul_lz(sel4(q, e, h, h, f), sel4(q, f, g, e, g));
+  typename TeLazy<F, K>::Ext o;
   o.x = quad_bcast<0>(m3);
   o.y = quad_bcast<1>(m3);
   o.t = quad_bcast<2>(m3);
   o.z = quad_bcast<3>(m3);
   return o;
 }
+__device__ __forceinline__ Te377::Ext add_quad(const Te377::Ext& a, const Te377::Ext& b, uint32_t q) { return te_add_quad<Fp, G1Consts>(a, b, q); }
 __device__ __forceinline__ Fp::El coord4(uint32_t q, const Te377::Ext& p) { return sel4(q, p.x, p.y, p.t, p.z); }
+__device__ __forceinline__ EdLazy::Ext add_quad(const EdLazy::Ext& a, const EdLazy::Ext& b, uint32_t q) { return te_add_quad<Fq, EdConsts>(a, b, q); }
+__device__ __forceinline__ Fq::El coord4(uint32_t q, const EdLazy::Ext& p) { return sel4(q, p.x, p.y, p.t, p.z); }
 
 // One reduction level r (same index scheme as k_tree_step) with a quad per addition.
 template <class CV>
@@ -1056,10 +1061,10 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, ws, x), load_bucket<CV>(buckets, ws, y), q);
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_EXCEPTIONAL);
   // each lane stores one coordinate
-  const Fp::El c = coord4(q, sum);
-  uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + 13 * q) * NB + x;
+  const typename CV::F::El c = coord4(q, sum);
+  uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + CV::NL * q) * NB + x;
 #pragma unroll
-  for (int j = 0; j < 13; j++) base[(size_t)j * NB] = c.l[j];
+  for (int j = 0; j < (int)CV::NL; j++) base[(size_t)j * NB] = c.l[j];
 }
 
 // Quad per split row: bucket += its overflow partials.
@@ -1086,10 +1091,10 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
       bad |= CV::is_bad(acc);
     }
     if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
-    const Fp::El c = coord4(q, acc);
-    uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + 13 * q) * NB + t;
+    const typename CV::F::El c = coord4(q, acc);
+    uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + CV::NL * q) * NB + t;
 #pragma unroll
-    for (int j = 0; j < 13; j++) base[(size_t)j * NB] = c.l[j];
+    for (int j = 0; j < (int)CV::NL; j++) base[(size_t)j * NB] = c.l[j];
   }
 }
 
