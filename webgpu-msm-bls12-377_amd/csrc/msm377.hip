@@ -364,26 +364,54 @@ __device__ __forceinline__ void digit_key(uint32_t biased, uint32_t& key, uint32
   sign = d < 0 ? 1u : 0u;
   key = (uint32_t)(d < 0 ? -d : d);
 }
-__device__ __forceinline__ uint32_t key_range(uint32_t key) { return key >= NB ? NRANGE - 1 : key / KRANGE; }
+// A window whose digits stay small (the top window: a 253-bit scalar leaves it 13 bits) would crowd all its
+// elements into a few of the 256 ranges -- regions far beyond what k_local_sort keeps in LDS.  The decomposition
+// records the largest key of window 15 and the sort narrows that window's ranges by a power of two (shift s:
+// 128 >> s keys per range, s <= 5) so that the keys in use still spread over the 256 regions; every other
+// window slot keeps the full width (key_max = NB).
+__device__ __forceinline__ uint32_t win_shift(uint32_t max_key) {
+  uint32_t s = 0;
+  while (s < 5 && max_key < (NB >> (s + 1))) s++;
+  return s;
+}
+__device__ __forceinline__ uint32_t key_range(uint32_t key, uint32_t s) {
+  return s == 0 ? (key >= NB ? NRANGE - 1 : key / KRANGE) : key >> (7 - s);
+}
 
 // One thread per scalar: 16 signed digits d_w in [-2^15, 2^15), stored biased (d + 2^15).
 // Only windows [wb, wb + wc) are written (window sharding); the carry chain always runs over
 // all 16.  A final carry (scalar >= 2^255 - 2^239) sets *err, as cuzk/utils.ts:95-98 throws.
 __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n,
-                                                   uint32_t wb, uint32_t wc, int* __restrict__ err) {
+                                                   uint32_t wb, uint32_t wc, int* __restrict__ err, uint32_t* __restrict__ top_key_max) {
+  // top_key_max (may be null): largest key of window 15, the one window that scalars below a 253-bit modulus leave
+  // mostly empty; see win_shift.  One LDS atomic per thread at worst, one global atomic per block.
+  __shared__ uint32_t wmax;
+  if (threadIdx.x == 0) wmax = 0;
+  __syncthreads();
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint32_t w[8];
-  load_words16(scalars + i * 8, w, 2);
-  uint32_t carry = 0;
+  if (i < n) {
+    uint32_t w[8];
+    load_words16(scalars + i * 8, w, 2);
+    uint32_t carry = 0;
 #pragma unroll
-  for (uint32_t win = 0; win < 16; win++) {
-    uint32_t limb = (w[win >> 1] >> (16 * (win & 1))) & 0xffffu;
-    uint32_t v = limb + carry;
-    carry = v >= 32768u ? 1u : 0u;
-    if (win >= wb && win < wb + wc) digits[(size_t)(win - wb) * n + i] = (uint16_t)((v + 32768u) & 0xffffu);
+    for (uint32_t win = 0; win < 16; win++) {
+      uint32_t limb = (w[win >> 1] >> (16 * (win & 1))) & 0xffffu;
+      uint32_t v = limb + carry;
+      carry = v >= 32768u ? 1u : 0u;
+      if (win >= wb && win < wb + wc) {
+        const uint32_t biased = (v + 32768u) & 0xffffu;
+        digits[(size_t)(win - wb) * n + i] = (uint16_t)biased;
+        if (win == 15 && top_key_max) {
+          uint32_t key, sign;
+          digit_key(biased, key, sign);
+          if (key > wmax) atomicMax(&wmax, key);
+        }
+      }
+    }
+    if (carry) atomicOr(err, 1);
   }
-  if (carry) atomicOr(err, 1);
+  __syncthreads();
+  if (threadIdx.x == 0 && top_key_max && wmax > *top_key_max) atomicMax(top_key_max, wmax);
 }
 
 // ---- GLV front end (the reference lists it as future work, README.md:562) ----
@@ -553,9 +581,10 @@ __device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ dg, 
 }
 
 __global__ void __launch_bounds__(1024) k_range_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts /* [ws][r][c] */,
-                                                      uint64_t n, uint32_t chunks, uint64_t per_chunk) {
+                                                      uint64_t n, uint32_t chunks, uint64_t per_chunk, const uint32_t* __restrict__ key_max) {
   __shared__ uint32_t cnt[NRANGE];
   const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t shift = win_shift(key_max[ws]);
   if (tid < NRANGE) cnt[tid] = 0;
   __syncthreads();
   const uint64_t beg = (uint64_t)c * per_chunk;
@@ -563,7 +592,7 @@ __global__ void __launch_bounds__(1024) k_range_count(const uint16_t* __restrict
   for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t, uint32_t biased) {
     uint32_t key, sign;
     digit_key(biased, key, sign);
-    atomicAdd(&cnt[key_range(key)], 1u);
+    atomicAdd(&cnt[key_range(key, shift)], 1u);
   });
   __syncthreads();
   if (tid < NRANGE) counts[((size_t)ws * NRANGE + tid) * chunks + c] = cnt[tid];
@@ -597,9 +626,11 @@ __global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ co
 }
 
 __global__ void __launch_bounds__(1024) k_partition(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
-                                                    SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk) {
+                                                    SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk,
+                                                    const uint32_t* __restrict__ key_max) {
   __shared__ uint32_t cur[NRANGE];
   const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t shift = win_shift(key_max[ws]);
   if (tid < NRANGE) cur[tid] = counts[((size_t)ws * NRANGE + tid) * chunks + c];
   __syncthreads();
   const uint64_t beg = (uint64_t)c * per_chunk;
@@ -608,7 +639,7 @@ __global__ void __launch_bounds__(1024) k_partition(const uint16_t* __restrict__
   for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t i, uint32_t biased) {
     uint32_t key, sign;
     digit_key(biased, key, sign);
-    out[atomicAdd(&cur[key_range(key)], 1u)] = SortElem{(uint32_t)i | (sign << 31), key};
+    out[atomicAdd(&cur[key_range(key, shift)], 1u)] = SortElem{(uint32_t)i | (sign << 31), key};
   });
 }
 
@@ -619,13 +650,16 @@ __global__ void __launch_bounds__(1024) k_partition(const uint16_t* __restrict__
 // the scatter pass; longer regions are streamed twice.
 constexpr uint32_t LS_CACHE = 6144;
 __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
-                                                    uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n) {
+                                                    uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
+                                                    const uint32_t* __restrict__ key_max) {
   __shared__ uint32_t bins[KRANGE + 1];
   __shared__ uint32_t part[256];
   __shared__ SortElem cache[LS_CACHE];
   const uint32_t r = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
-  const uint32_t lo = r * KRANGE;
-  const bool last = r == NRANGE - 1;
+  const uint32_t shift = win_shift(key_max[ws]);
+  const uint32_t KR = KRANGE >> shift;  // keys per range in this window
+  const uint32_t lo = r * KR;
+  const bool last = shift == 0 && r == NRANGE - 1;  // only the full-width layout reaches key 32768
   const uint32_t rbeg = region_base[ws * (NRANGE + 1) + r], rend = region_base[ws * (NRANGE + 1) + r + 1];
   const uint32_t len = rend - rbeg;
   const bool cached = len <= LS_CACHE;
@@ -650,7 +684,7 @@ __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__
     }
   }
   __syncthreads();
-  const uint32_t own = tid < KRANGE ? bins[tid] : 0u;
+  const uint32_t own = tid < KR ? bins[tid] : 0u;
   part[tid] = own;
   __syncthreads();
   for (uint32_t off = 1; off < 256; off <<= 1) {
@@ -662,7 +696,7 @@ __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__
   uint32_t* rp = row_ptr + (size_t)ws * RP + lo;
   const uint32_t start = rbeg + part[tid] - own;
   __syncthreads();
-  if (tid < KRANGE) {
+  if (tid < KR) {
     bins[tid] = start;
     rp[tid] = start;
   }
@@ -670,6 +704,15 @@ __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__
     bins[KRANGE] = start + own;
     rp[KRANGE] = start + own;
     rp[KRANGE + 1] = rend;
+  }
+  if (shift) {  // narrowed ranges cover keys below NRANGE * KR only: every row above is empty and starts at the end
+    const uint32_t covered = NRANGE * KR, total = region_base[ws * (NRANGE + 1) + NRANGE];
+    const uint32_t per_block = (RP - covered + NRANGE - 1) / NRANGE;
+    uint32_t* rp_w = row_ptr + (size_t)ws * RP;
+    for (uint32_t j = tid; j < per_block; j += 256) {
+      const uint32_t idx = covered + r * per_block + j;
+      if (idx < RP) rp_w[idx] = total;
+    }
   }
   __syncthreads();
   uint32_t* vi = val_idx + (size_t)ws * n;
@@ -1268,6 +1311,7 @@ struct msm377_ctx {
   uint16_t* d_digits = nullptr;       // 16 x cap
   uint32_t* d_range_counts = nullptr; // 16 x NRANGE x chunks: per-chunk range counts, then write offsets
   uint32_t* d_region_base = nullptr;  // 16 x (NRANGE + 1)
+  uint32_t* d_key_max = nullptr;      // 16: largest sort key per window slot (win_shift)
   SortElem* d_sort_temp = nullptr;    // 16 x cap partitioned (index|sign, key) pairs
   uint32_t* d_row_ptr = nullptr;      // 16 x RP
   uint32_t* d_val_idx = nullptr;      // 16 x cap
@@ -1318,6 +1362,7 @@ struct msm377_ctx {
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
   uint32_t upload_split_pct = 55;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 10..90)
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
+  bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;
   int tail_threads = 4;               // MSM377_TAIL_THREADS=1: single-threaded host tail
   int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
@@ -1478,13 +1523,19 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   WorkItem* work = ctx->d_work + pv.work_off;
   uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::PT_WORDS;
   const uint32_t* bases = ctx->d_bases + ph.base_first * BP::REC_WORDS;
+  uint32_t* key_max = ctx->d_key_max + pv.ws0;
   if (ph.front) {
+  // largest key per window slot: NB (full-width ranges) except for window 15 of the plain front end, which
+  // k_decompose measures
+  HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)key_max, (int)NB, wc, st));
+  uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
+  if (top_key_max) HIP_TRY(ctx, hipMemsetAsync(top_key_max, 0, 4, st));
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (glv)
       hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n_scalars, pv.wb, wc, d_err);
     else
-      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err);
+      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err, top_key_max);
     HIP_TRY(ctx, hipGetLastError());
   }
 
@@ -1494,13 +1545,13 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     const uint64_t want = (n + 4095) / 4096;  // at least ~4096 elements per block
     if (chunks > want) chunks = (uint32_t)(want ? want : 1);
     const uint64_t per_chunk = (n + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, n, chunks, per_chunk);
+    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, n, chunks, per_chunk, key_max);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, range_counts, region_base, chunks);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_partition, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk);
+    hipLaunchKernelGGL(k_partition, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk, key_max);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n);
+    hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -1853,6 +1904,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 10), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
@@ -1882,6 +1934,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_range_counts, (size_t)NRANGE * MAX_SORT_BLOCKS * 4);  // chunks * wc <= MAX_SORT_BLOCKS
   dalloc((void**)&ctx->d_region_base, (size_t)MSM377_NUM_WINDOWS * (NRANGE + 1) * 4);
+  dalloc((void**)&ctx->d_key_max, (size_t)MSM377_NUM_WINDOWS * 4);
   dalloc((void**)&ctx->d_sort_temp, cap * MSM377_NUM_WINDOWS * sizeof(SortElem));
   dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
@@ -1912,7 +1965,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
-  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
+  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_key_max, ctx->d_sort_temp,
                   ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
