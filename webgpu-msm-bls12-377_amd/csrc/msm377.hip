@@ -369,7 +369,10 @@ __device__ __forceinline__ void digit_key(uint32_t biased, uint32_t& key, uint32
 // records the largest key of window 15 and the sort narrows that window's ranges by a power of two (shift s:
 // 128 >> s keys per range, s <= 5) so that the keys in use still spread over the 256 regions; every other
 // window slot keeps the full width (key_max = NB).
-__device__ __forceinline__ uint32_t win_shift(uint32_t max_key) {
+constexpr uint32_t KEY_TRACKED = 0x80000000u;  // key_max word: bit 31 = "measured", low bits = largest key; 0 = not measured
+__device__ __forceinline__ uint32_t win_shift(uint32_t key_max_word) {
+  if (!(key_max_word & KEY_TRACKED)) return 0;
+  const uint32_t max_key = key_max_word & ~KEY_TRACKED;
   uint32_t s = 0;
   while (s < 5 && max_key < (NB >> (s + 1))) s++;
   return s;
@@ -404,7 +407,7 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ 
         if (win == 15 && top_key_max) {
           uint32_t key, sign;
           digit_key(biased, key, sign);
-          if (key > wmax) atomicMax(&wmax, key);
+          if ((key | KEY_TRACKED) > wmax) atomicMax(&wmax, key | KEY_TRACKED);
         }
       }
     }
@@ -1311,7 +1314,6 @@ struct msm377_ctx {
   uint16_t* d_digits = nullptr;       // 16 x cap
   uint32_t* d_range_counts = nullptr; // 16 x NRANGE x chunks: per-chunk range counts, then write offsets
   uint32_t* d_region_base = nullptr;  // 16 x (NRANGE + 1)
-  uint32_t* d_key_max = nullptr;      // 16: largest sort key per window slot (win_shift)
   SortElem* d_sort_temp = nullptr;    // 16 x cap partitioned (index|sign, key) pairs
   uint32_t* d_row_ptr = nullptr;      // 16 x RP
   uint32_t* d_val_idx = nullptr;      // 16 x cap
@@ -1481,6 +1483,7 @@ uint32_t auto_seg(const msm377_ctx* ctx, uint64_t entries, bool glv) {
   return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, SEG_MIN), SEG_MAX);
 }
 
+constexpr uint32_t META_BLOCK_WORDS = 2 * SEG_BINS + 4 + MSM377_NUM_WINDOWS;  // per pipeline part: work-list counters + key_max words
 constexpr uint64_t PIPELINE_MIN_ENTRIES = 1ull << 21;  // (windows x points) below which a call stays in one part
 
 constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot
@@ -1523,13 +1526,13 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   WorkItem* work = ctx->d_work + pv.work_off;
   uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::PT_WORDS;
   const uint32_t* bases = ctx->d_bases + ph.base_first * BP::REC_WORDS;
-  uint32_t* key_max = ctx->d_key_max + pv.ws0;
+  uint32_t* meta_block = ctx->d_work_meta + (size_t)part * META_BLOCK_WORDS;  // [work-list counters | key_max[16]]
+  uint32_t* key_max = meta_block + (2 * SEG_BINS + 4);
   if (ph.front) {
-  // largest key per window slot: NB (full-width ranges) except for window 15 of the plain front end, which
-  // k_decompose measures
-  HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)key_max, (int)NB, wc, st));
+  // One memset clears this part's work-list counters AND its key_max words (0 = full-width ranges); k_decompose
+  // then measures window 15 of the plain front end.
+  HIP_TRY(ctx, hipMemsetAsync(meta_block, 0, (size_t)META_BLOCK_WORDS * 4, st));
   uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
-  if (top_key_max) HIP_TRY(ctx, hipMemsetAsync(top_key_max, 0, 4, st));
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (glv)
@@ -1557,12 +1560,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   {
     StageTimer t(ctx, MSM377_STAGE_ACCUMULATE, st, part);
     const uint32_t rows = wc * NB;
-    uint32_t* meta = ctx->d_work_meta + (size_t)part * (2 * SEG_BINS + 4);
+    uint32_t* meta = meta_block;
     uint32_t* work_hist = meta;
     uint32_t* cursor = meta + SEG_BINS;
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
-    HIP_TRY(ctx, hipMemsetAsync(meta, 0, (size_t)(2 * SEG_BINS + 4) * 4, st));
     hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, row_ptr, rows, SEG, work_hist, row_ovf_base, counters, split_rows);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total);
@@ -1934,14 +1936,13 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_range_counts, (size_t)NRANGE * MAX_SORT_BLOCKS * 4);  // chunks * wc <= MAX_SORT_BLOCKS
   dalloc((void**)&ctx->d_region_base, (size_t)MSM377_NUM_WINDOWS * (NRANGE + 1) * 4);
-  dalloc((void**)&ctx->d_key_max, (size_t)MSM377_NUM_WINDOWS * 4);
   dalloc((void**)&ctx->d_sort_temp, cap * MSM377_NUM_WINDOWS * sizeof(SortElem));
   dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
   dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
   dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * sizeof(WorkItem));
-  dalloc((void**)&ctx->d_work_meta, (size_t)2 * (2 * SEG_BINS + 4) * 4);  // one block per pipeline part
+  dalloc((void**)&ctx->d_work_meta, (size_t)2 * META_BLOCK_WORDS * 4);  // one block per pipeline part
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * PT_WORDS * 4);
@@ -1965,7 +1966,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
-  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_key_max, ctx->d_sort_temp,
+  void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
                   ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
