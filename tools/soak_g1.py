@@ -1,0 +1,44 @@
+"""Randomized parity soak (not part of the test suite): sizes 1..100003, uniform / short / skewed / near-r scalars,
+all three internal paths, host (chunked upload forced from 3000 points), device and fixed-base entry points, against
+the CPU oracle.  Runs for ~150 s; exit code 1 on any mismatch."""
+import os, sys, random, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+os.environ["MSM377_UPLOAD_CHUNK_MIN"] = "3000"
+import torch
+import webgpu_msm_bls12_377_amd as msm
+import util, pyref as R
+oracle = util.load_oracle()
+eng = msm.MsmEngine(1 << 17)
+rnd = random.Random(20261004)
+t0 = time.time(); bad = 0; cases = 0
+while time.time() - t0 < 150:
+    n = rnd.choice([1, 2, 3, 5, 17, 64, 65, 255, 256, 257, 1000, 2999, 3000, 3001, 4096, 10000, 33333, 65536, 100003])
+    seed = rnd.randrange(1 << 30)
+    r2 = random.Random(seed)
+    pts = util.oracle_gen_points(oracle, n, r2.randrange(1, 1 << 200), r2.randrange(1, 1 << 200))
+    ks = R.encode_scalars(R.rand_scalars(seed, n))
+    mode = rnd.choice(["uniform", "small", "skew", "top"])
+    if mode == "small":
+        ks = R.encode_scalars([rnd.randrange(1 << rnd.choice([1, 16, 17, 64, 128])) for _ in range(n)])
+    elif mode == "skew":
+        hot = R.rand_scalars(seed, 3)
+        ks = R.encode_scalars([rnd.choice(hot) if rnd.random() < 0.9 else rnd.randrange(R.R_ORDER) for _ in range(n)])
+    elif mode == "top":
+        ks = R.encode_scalars([R.R_ORDER - 1 - rnd.randrange(1 << 20) for _ in range(n)])
+    exp = util.oracle_msm(oracle, pts, ks)
+    for form, glv in (("edwards", "auto"), ("weierstrass", False), ("weierstrass", True)):
+        eng.set_g1_form(form); eng.set_glv(glv)
+        got = eng.msm(pts, ks)
+        if got != exp:
+            bad += 1
+            print("MISMATCH", n, seed, mode, form, glv, flush=True)
+    eng.set_g1_form("edwards"); eng.set_glv("auto")
+    d_p = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda(); d_s = torch.frombuffer(bytearray(ks), dtype=torch.uint8).cuda()
+    if eng.msm_device(d_p.data_ptr(), d_s.data_ptr(), n) != exp:
+        bad += 1; print("MISMATCH device", n, seed, mode, flush=True)
+    eng.set_bases(pts)
+    if eng.msm_fixed_base(ks) != exp:
+        bad += 1; print("MISMATCH fixed", n, seed, mode, flush=True)
+    cases += 1
+print("soak: %d cases, %d mismatches" % (cases, bad))
+sys.exit(1 if bad else 0)
