@@ -8,6 +8,7 @@ import pytest
 
 import pyref as R
 import util
+import webgpu_msm_bls12_377_amd as msm
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +45,21 @@ def test_2_16_against_reference_sized_oracle(engine, oracle):
     assert engine.ed_msm(pts, ks) == exp
     d_p, d_s = dev(pts), dev(ks)
     assert engine.ed_msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == exp
+
+
+def test_host_buffers_upload_in_two_chunks(oracle, monkeypatch):
+    """msm377_ed_msm with large host buffers: two chunks of points, the second accumulating on top of the first
+    (forced at small sizes through MSM377_UPLOAD_CHUNK_MIN)."""
+    monkeypatch.setenv("MSM377_UPLOAD_CHUNK_MIN", "100")
+    eng = msm.MsmEngine(1 << 17)
+    try:
+        for n in (128, 131, 1000, 4097, 70001):
+            rnd = random.Random(900 + n)
+            pts = util.oracle_ed_gen_points(oracle, n, rnd.randrange(1, 1 << 200), rnd.randrange(1, 1 << 200))
+            ks = R.encode_scalars([rnd.randrange(R.R_ORDER) for _ in range(n)])
+            assert eng.ed_msm(pts, ks) == util.oracle_ed_msm(oracle, pts, ks), n
+    finally:
+        eng.close()
 
 
 def test_one_repeated_point_and_opposites(engine):

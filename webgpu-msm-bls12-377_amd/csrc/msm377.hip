@@ -2138,6 +2138,46 @@ int msm377_ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
   }
   if (n == 0) return msm377_ed_msm_device(ctx, nullptr, nullptr, 0, out_xy);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n >= ctx->upload_chunk_min) {  // two chunks of points, like msm377_g1_msm: chunk A computes while chunk B uploads
+    const uint64_t nA = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull), nB = n - nA;
+    const size_t sc_stage = (size_t)ctx->cap * 96;
+    const uint32_t* d_sc = ctx->d_raw_scalars;
+    const uint32_t* d_pt = ctx->d_raw_points;
+    int rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, nA * 32, sc_stage);
+    if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_points, points, nA * 64, 0);
+    if (rc) return rc;
+    int up_rc = MSM377_OK;
+    std::thread upload([&] {
+      if (hipSetDevice(ctx->device) != hipSuccess) {
+        up_rc = MSM377_EHIP;
+        return;
+      }
+      up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + nA * 32, scalars + nA * 32, nB * 32, sc_stage + nA * 32);
+      if (up_rc == MSM377_OK) up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + nA * 64, points + nA * 64, nB * 64, nA * 64);
+    });
+    ctx->bases_n = 0;
+    Phase pa, pb;
+    pa.back = false;
+    pb.clear_err = false;
+    pb.into = true;
+    pb.base_first = nA;
+    rc = convert_bases<EdDev>(ctx, d_pt, nA);
+    if (rc == MSM377_OK) rc = enqueue_windows<EdDev>(ctx, d_sc, nA, 0, MSM377_NUM_WINDOWS, 0, false, pa);
+    upload.join();
+    if (rc == MSM377_OK) rc = up_rc;
+    if (rc == MSM377_OK) rc = convert_bases<EdDev>(ctx, d_pt + nA * 16, nB, nA, false);
+    if (rc == MSM377_OK) rc = enqueue_windows<EdDev>(ctx, d_sc + nA * 8, nB, 0, MSM377_NUM_WINDOWS, 0, false, pb);
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+    rc = finish_windows(ctx, 0);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    edh_combine(ctx->h_partials, out_xy);
+    time_tail(ctx, t0);
+    return MSM377_OK;
+  }
   int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 64, 0);
   if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
   if (rc) return rc;
