@@ -8,9 +8,10 @@ n = 1 << 20
 d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
 scal = bench.seeded_scalars(0x5CA1A5, n)
 engs = {}
-for name, v, split in (("chunked 55", "262144", "55"), ("chunked 60", "262144", "60"), ("chunked 65", "262144", "65"), ("chunked 70", "262144", "70"), ("whole", "99999999999", "50")):
+for name, v, split, k in (("4 chunks 30", "262144", "30", "4"), ("5 chunks 25", "262144", "25", "5"), ("6 chunks 20", "262144", "20", "6"), ("8 chunks 15", "262144", "15", "8"), ("4 chunks 25", "262144", "25", "4"), ("whole", "99999999999", "50", "2")):
     os.environ["MSM377_UPLOAD_CHUNK_MIN"] = v
     os.environ["MSM377_UPLOAD_SPLIT"] = split
+    os.environ["MSM377_UPLOAD_CHUNKS"] = k
     engs[name] = msm.MsmEngine(n, device=0)
 engs["whole"].generate_bases_device(0x377, n, d_points.data_ptr())
 pts = d_points.cpu().numpy().tobytes()

@@ -1362,7 +1362,8 @@ struct msm377_ctx {
   hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
   hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
-  uint32_t upload_split_pct = 55;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 10..90)
+  uint32_t upload_chunks = 4;              // chunks of the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..8): 2: 5.07, 3: 4.89, 4-6: 4.70, 8: 4.95 ms at 2^20
+  uint32_t upload_split_pct = 30;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 10..90)
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;
@@ -1904,6 +1905,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 8);
   if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 10), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
@@ -2032,38 +2034,58 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
   const uint32_t* d_pt = ctx->d_raw_points;
   int rc;
   if (n >= ctx->upload_chunk_min && form != TABLE_XYZZ_GLV) {
-    // Large inputs in host memory: the upload (3.3 ms for 2^20 points from pageable memory) is as long as the whole
-    // computation, so the MSM runs as TWO chunks of points: chunk A's decompose .. accumulate .. merge runs while
-    // chunk B is on its way, chunk B accumulates on top of A's buckets (Phase::into), and reduction and tail run once.
-    const uint64_t nA = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull), nB = n - nA;
+    // Large inputs in host memory: the upload (2.9 ms for 2^20 points from pageable memory) is as long as the whole
+    // computation, so the MSM runs as K chunks of points: a chunk's decompose .. accumulate .. merge runs while the
+    // next one is on its way, later chunks accumulate on top of the buckets (Phase::into), and reduction and tail
+    // run once.
+    uint64_t cut[10];  // chunk c = points [cut[c], cut[c + 1]): the first one upload_split_pct of n, the rest even
+    uint32_t K = 0;
+    cut[0] = 0;
+    for (uint32_t c = 1; c < ctx->upload_chunks; c++) {
+      const uint64_t first_end = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull);
+      const uint64_t b = c == 1 ? first_end : (first_end + (n - first_end) * (c - 1) / (ctx->upload_chunks - 1)) & ~63ull;
+      if (b > cut[K] && b < n) cut[++K] = b;  // no empty chunks (small n)
+    }
+    cut[++K] = n;
     const size_t sc_stage = (size_t)ctx->cap * 96;
-    rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, nA * 32, sc_stage);
-    if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_points, points, nA * 96, 0);
+    auto upload_chunk = [&](uint32_t c) -> int {
+      const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+      int r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + first * 32, scalars + first * 32, cnt * 32, sc_stage + first * 32);
+      if (r == MSM377_OK) r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * 96, points + first * 96, cnt * 96, first * 96);
+      return r;
+    };
+    rc = upload_chunk(0);
     if (rc) return rc;
     int up_rc = MSM377_OK;
+    std::atomic<uint32_t> uploaded{1};  // chunks on the device so far
+    std::atomic<bool> upload_done{false};
     std::thread upload([&] {
-      if (hipSetDevice(ctx->device) != hipSuccess) {
-        up_rc = MSM377_EHIP;
-        return;
+      if (hipSetDevice(ctx->device) != hipSuccess) up_rc = MSM377_EHIP;
+      for (uint32_t c = 1; c < K && up_rc == MSM377_OK; c++) {
+        up_rc = upload_chunk(c);
+        if (up_rc == MSM377_OK) uploaded.store(c + 1, std::memory_order_release);
       }
-      up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + nA * 32, scalars + nA * 32, nB * 32, sc_stage + nA * 32);
-      if (up_rc == MSM377_OK) up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + nA * 96, points + nA * 96, nB * 96, nA * 96);
+      upload_done.store(true, std::memory_order_release);
     });
     const bool te = form == TABLE_TE;
-    Phase pa, pb;
-    pa.back = false;
-    pb.clear_err = false;
-    pb.into = true;
-    pb.base_first = nA;
-    rc = te ? convert_bases<TeDev>(ctx, d_pt, nA) : convert_bases<G1Dev>(ctx, d_pt, nA);
-    if (rc == MSM377_OK)
-      rc = te ? enqueue_windows<TeDev>(ctx, d_sc, nA, 0, MSM377_NUM_WINDOWS, 0, false, pa) : enqueue_windows<G1Dev>(ctx, d_sc, nA, 0, MSM377_NUM_WINDOWS, 0, false, pa);
+    for (uint32_t c = 0; c < K && rc == MSM377_OK; c++) {
+      while (uploaded.load(std::memory_order_acquire) <= c && !upload_done.load(std::memory_order_acquire)) std::this_thread::yield();
+      if (uploaded.load(std::memory_order_acquire) <= c) {  // the upload thread stopped on an error
+        rc = up_rc ? up_rc : MSM377_EHIP;
+        break;
+      }
+      const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+      Phase ph;
+      ph.clear_err = c == 0;
+      ph.into = c > 0;
+      ph.back = c + 1 == K;
+      ph.base_first = first;
+      rc = te ? convert_bases<TeDev>(ctx, d_pt + first * 24, cnt, first, c == 0) : convert_bases<G1Dev>(ctx, d_pt + first * 24, cnt, first, c == 0);
+      if (rc == MSM377_OK)
+        rc = te ? enqueue_windows<TeDev>(ctx, d_sc + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph)
+                : enqueue_windows<G1Dev>(ctx, d_sc + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+    }
     upload.join();
-    if (rc == MSM377_OK) rc = up_rc;
-    if (rc == MSM377_OK) rc = te ? convert_bases<TeDev>(ctx, d_pt + nA * 24, nB, nA, false) : convert_bases<G1Dev>(ctx, d_pt + nA * 24, nB, nA, false);
-    if (rc == MSM377_OK)
-      rc = te ? enqueue_windows<TeDev>(ctx, d_sc + nA * 8, nB, 0, MSM377_NUM_WINDOWS, 0, false, pb)
-              : enqueue_windows<G1Dev>(ctx, d_sc + nA * 8, nB, 0, MSM377_NUM_WINDOWS, 0, false, pb);
     if (rc) {
       (void)hipStreamSynchronize(ctx->stream);
       return rc;
