@@ -1850,6 +1850,62 @@ int resident_table_to_weierstrass(msm377_ctx* ctx) {
   return MSM377_OK;
 }
 
+// Host-buffer entry points with large inputs: the upload (2.9 ms for 2^20 G1 points from pageable memory) is as
+// long as the whole computation, so the MSM runs as K chunks of points: a chunk's decompose .. accumulate .. merge
+// runs while the next one is on its way, later chunks accumulate on top of the buckets (Phase::into), and reduction,
+// gather and D2H are queued once, with the last chunk.  Returns with everything enqueued (slot 0).
+template <class CV>
+int run_chunked_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n) {
+  constexpr size_t PB = CV::RAW_WORDS * 4;  // bytes per wire point
+  uint64_t cut[10];  // chunk c = points [cut[c], cut[c + 1]): the first one upload_split_pct of n, the rest even
+  uint32_t K = 0;
+  cut[0] = 0;
+  for (uint32_t c = 1; c < ctx->upload_chunks; c++) {
+    const uint64_t first_end = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull);
+    const uint64_t b = c == 1 ? first_end : (first_end + (n - first_end) * (c - 1) / (ctx->upload_chunks - 1)) & ~63ull;
+    if (b > cut[K] && b < n) cut[++K] = b;  // no empty chunks (small n)
+  }
+  cut[++K] = n;
+  const size_t sc_stage = (size_t)ctx->cap * 96;
+  auto upload_chunk = [&](uint32_t c) -> int {
+    const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+    int r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + first * 32, scalars + first * 32, cnt * 32, sc_stage + first * 32);
+    if (r == MSM377_OK) r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * PB, points + first * PB, cnt * PB, first * PB);
+    return r;
+  };
+  int rc = upload_chunk(0);
+  if (rc) return rc;
+  int up_rc = MSM377_OK;
+  std::atomic<uint32_t> uploaded{1};  // chunks on the device so far
+  std::atomic<bool> upload_done{false};
+  std::thread upload([&] {
+    if (hipSetDevice(ctx->device) != hipSuccess) up_rc = MSM377_EHIP;
+    for (uint32_t c = 1; c < K && up_rc == MSM377_OK; c++) {
+      up_rc = upload_chunk(c);
+      if (up_rc == MSM377_OK) uploaded.store(c + 1, std::memory_order_release);
+    }
+    upload_done.store(true, std::memory_order_release);
+  });
+  for (uint32_t c = 0; c < K && rc == MSM377_OK; c++) {
+    while (uploaded.load(std::memory_order_acquire) <= c && !upload_done.load(std::memory_order_acquire)) std::this_thread::yield();
+    if (uploaded.load(std::memory_order_acquire) <= c) {  // the upload thread stopped on an error
+      rc = up_rc ? up_rc : MSM377_EHIP;
+      break;
+    }
+    const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+    Phase ph;
+    ph.clear_err = c == 0;
+    ph.into = c > 0;
+    ph.back = c + 1 == K;
+    ph.base_first = first;
+    rc = convert_bases<CV>(ctx, ctx->d_raw_points + first * CV::RAW_WORDS, cnt, first, c == 0);
+    if (rc == MSM377_OK) rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+  }
+  upload.join();
+  if (rc) (void)hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+
 int check_args(msm377_ctx* ctx, const void* a, const void* b, uint64_t n, bool need_a) {
   if (!ctx) return MSM377_EINVAL;
   ctx->err.clear();
@@ -2034,62 +2090,9 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
   const uint32_t* d_pt = ctx->d_raw_points;
   int rc;
   if (n >= ctx->upload_chunk_min && form != TABLE_XYZZ_GLV) {
-    // Large inputs in host memory: the upload (2.9 ms for 2^20 points from pageable memory) is as long as the whole
-    // computation, so the MSM runs as K chunks of points: a chunk's decompose .. accumulate .. merge runs while the
-    // next one is on its way, later chunks accumulate on top of the buckets (Phase::into), and reduction and tail
-    // run once.
-    uint64_t cut[10];  // chunk c = points [cut[c], cut[c + 1]): the first one upload_split_pct of n, the rest even
-    uint32_t K = 0;
-    cut[0] = 0;
-    for (uint32_t c = 1; c < ctx->upload_chunks; c++) {
-      const uint64_t first_end = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull);
-      const uint64_t b = c == 1 ? first_end : (first_end + (n - first_end) * (c - 1) / (ctx->upload_chunks - 1)) & ~63ull;
-      if (b > cut[K] && b < n) cut[++K] = b;  // no empty chunks (small n)
-    }
-    cut[++K] = n;
-    const size_t sc_stage = (size_t)ctx->cap * 96;
-    auto upload_chunk = [&](uint32_t c) -> int {
-      const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
-      int r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + first * 32, scalars + first * 32, cnt * 32, sc_stage + first * 32);
-      if (r == MSM377_OK) r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * 96, points + first * 96, cnt * 96, first * 96);
-      return r;
-    };
-    rc = upload_chunk(0);
-    if (rc) return rc;
-    int up_rc = MSM377_OK;
-    std::atomic<uint32_t> uploaded{1};  // chunks on the device so far
-    std::atomic<bool> upload_done{false};
-    std::thread upload([&] {
-      if (hipSetDevice(ctx->device) != hipSuccess) up_rc = MSM377_EHIP;
-      for (uint32_t c = 1; c < K && up_rc == MSM377_OK; c++) {
-        up_rc = upload_chunk(c);
-        if (up_rc == MSM377_OK) uploaded.store(c + 1, std::memory_order_release);
-      }
-      upload_done.store(true, std::memory_order_release);
-    });
     const bool te = form == TABLE_TE;
-    for (uint32_t c = 0; c < K && rc == MSM377_OK; c++) {
-      while (uploaded.load(std::memory_order_acquire) <= c && !upload_done.load(std::memory_order_acquire)) std::this_thread::yield();
-      if (uploaded.load(std::memory_order_acquire) <= c) {  // the upload thread stopped on an error
-        rc = up_rc ? up_rc : MSM377_EHIP;
-        break;
-      }
-      const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
-      Phase ph;
-      ph.clear_err = c == 0;
-      ph.into = c > 0;
-      ph.back = c + 1 == K;
-      ph.base_first = first;
-      rc = te ? convert_bases<TeDev>(ctx, d_pt + first * 24, cnt, first, c == 0) : convert_bases<G1Dev>(ctx, d_pt + first * 24, cnt, first, c == 0);
-      if (rc == MSM377_OK)
-        rc = te ? enqueue_windows<TeDev>(ctx, d_sc + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph)
-                : enqueue_windows<G1Dev>(ctx, d_sc + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph);
-    }
-    upload.join();
-    if (rc) {
-      (void)hipStreamSynchronize(ctx->stream);
-      return rc;
-    }
+    rc = te ? run_chunked_upload<TeDev>(ctx, points, scalars, n) : run_chunked_upload<G1Dev>(ctx, points, scalars, n);
+    if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     if (!(te && (ctx->h_err[0] & ERR_TE_EXCEPTIONAL))) {
       rc = finish_windows(ctx, 0);
@@ -2160,39 +2163,10 @@ int msm377_ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
   }
   if (n == 0) return msm377_ed_msm_device(ctx, nullptr, nullptr, 0, out_xy);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (n >= ctx->upload_chunk_min) {  // two chunks of points, like msm377_g1_msm: chunk A computes while chunk B uploads
-    const uint64_t nA = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull), nB = n - nA;
-    const size_t sc_stage = (size_t)ctx->cap * 96;
-    const uint32_t* d_sc = ctx->d_raw_scalars;
-    const uint32_t* d_pt = ctx->d_raw_points;
-    int rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, nA * 32, sc_stage);
-    if (rc == MSM377_OK) rc = h2d_staged(ctx, ctx->d_raw_points, points, nA * 64, 0);
-    if (rc) return rc;
-    int up_rc = MSM377_OK;
-    std::thread upload([&] {
-      if (hipSetDevice(ctx->device) != hipSuccess) {
-        up_rc = MSM377_EHIP;
-        return;
-      }
-      up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + nA * 32, scalars + nA * 32, nB * 32, sc_stage + nA * 32);
-      if (up_rc == MSM377_OK) up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + nA * 64, points + nA * 64, nB * 64, nA * 64);
-    });
+  if (n >= ctx->upload_chunk_min) {  // chunks of points, like msm377_g1_msm: a chunk computes while the next one uploads
     ctx->bases_n = 0;
-    Phase pa, pb;
-    pa.back = false;
-    pb.clear_err = false;
-    pb.into = true;
-    pb.base_first = nA;
-    rc = convert_bases<EdDev>(ctx, d_pt, nA);
-    if (rc == MSM377_OK) rc = enqueue_windows<EdDev>(ctx, d_sc, nA, 0, MSM377_NUM_WINDOWS, 0, false, pa);
-    upload.join();
-    if (rc == MSM377_OK) rc = up_rc;
-    if (rc == MSM377_OK) rc = convert_bases<EdDev>(ctx, d_pt + nA * 16, nB, nA, false);
-    if (rc == MSM377_OK) rc = enqueue_windows<EdDev>(ctx, d_sc + nA * 8, nB, 0, MSM377_NUM_WINDOWS, 0, false, pb);
-    if (rc) {
-      (void)hipStreamSynchronize(ctx->stream);
-      return rc;
-    }
+    int rc = run_chunked_upload<EdDev>(ctx, points, scalars, n);
+    if (rc) return rc;
     rc = finish_windows(ctx, 0);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
