@@ -139,10 +139,13 @@ def side_workload(args, torch, msm, n):
         if cpu != res:
             raise SystemExit("PARITY FAILURE: HIP Edwards result differs from the CPU oracle")
         eng.ed_msm(ph, ks)  # host-buffer entry point (chunked upload): first call allocates the staging buffer
-        t1 = time.perf_counter()
-        r2 = eng.ed_msm(ph, ks)
-        out["ms_incl_h2d"] = round((time.perf_counter() - t1) * 1e3, 3)
-        assert r2 == res
+        samples = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            r2 = eng.ed_msm(ph, ks)
+            samples.append((time.perf_counter() - t1) * 1e3)
+            assert r2 == res
+        out["ms_incl_h2d"] = round(sorted(samples)[2], 3)
         out["cpu_baseline"] = {"value": round(cpu_ms, 1), "unit": "ms per 2^%d MSM" % args.log_n, "cores": int(oracle.oracle_omp_threads()),
                                "kind": "port", "sample": "the full workload, 1 run, same inputs; bit-exact with the GPU's"}
     print(json.dumps(out), flush=True)
@@ -310,10 +313,13 @@ def main():
             t1 = time.perf_counter()
             r2 = eng.msm(points_host, scalars_host)  # first call also allocates the pinned staging buffer
             out["ms_incl_h2d_first_call"] = round((time.perf_counter() - t1) * 1e3, 3)
-            t1 = time.perf_counter()
-            r2 = eng.msm(points_host, scalars_host)
-            out["ms_incl_h2d"] = round((time.perf_counter() - t1) * 1e3, 3)
-            assert r2 == result
+            samples = []
+            for _ in range(5):  # chunked upload overlapped with the computation (msm377_g1_msm); median of 5 calls
+                t1 = time.perf_counter()
+                r2 = eng.msm(points_host, scalars_host)
+                samples.append((time.perf_counter() - t1) * 1e3)
+                assert r2 == result
+            out["ms_incl_h2d"] = round(sorted(samples)[2], 3)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import util  # the CPU oracle: checker + cpu_baseline leg only
 
