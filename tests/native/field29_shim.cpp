@@ -94,7 +94,7 @@ int shim_te_sum(const uint32_t* q24s, const uint8_t* negs, uint32_t count, uint3
     for (uint32_t k = part; k < count; k += parts) {
       const Te377::PBase b = Te377::from_wire(q24s + 24 * k, q24s + 24 * k + 12, phi != 0);
       bad |= Fp::is_zero(b.z2);
-      acc = Te377::madd(acc, b, negs[k] != 0);
+      acc = k == part ? Te377::from_base(b, negs[k] != 0) : Te377::madd(acc, b, negs[k] != 0);  // k_accumulate: the first entry needs no addition
       bad |= Te377::is_bad(acc);
     }
     total = Te377::add(total, acc);
@@ -117,7 +117,7 @@ int shim_te_sum_affine(const uint32_t* q24s, const uint8_t* negs, uint32_t count
     bool b0;
     const Te377::ABase b = Te377::affine_from_wire(q24s + 24 * k, q24s + 24 * k + 12, b0);
     bad |= b0;
-    acc = Te377::madd_affine(acc, b, negs[k] != 0);
+    acc = k == 0 ? Te377::from_base_affine(b, negs[k] != 0) : Te377::madd_affine(acc, b, negs[k] != 0);
     bad |= Te377::is_bad(acc);
   }
   teh_to_wire(te_to_host(acc), out96);

@@ -201,7 +201,7 @@ def main():
     g1_extra = {"GEN_X": GX, "GEN_Y": GY, "B3": 3, "BETA": GLV_BETA,
                 # twisted Edwards form (csrc/te377.hpp): Montgomery forms of s, c s, 2d; and the raw (non-Montgomery)
                 # multipliers s R, c s R that take a RAW wire coordinate straight to the Montgomery form of s x, c s x
-                "TE_S": s_, "TE_CS": c_ * s_, "TE_2D": 2 * d_, "TE_SR": s_ * R29, "TE_CSR": c_ * s_ * R29,
+                "TE_S": s_, "TE_CS": c_ * s_, "TE_2D": 2 * d_, "TE_INV_D": pow(d_, -1, P), "TE_SR": s_ * R29, "TE_CSR": c_ * s_ * R29,
                 "TE_SBR": s_ * GLV_BETA * R29, "TE_CSBR": c_ * s_ * GLV_BETA * R29}
     s += emit("G1Consts", P, 13, g1_extra, rs=14, lazy=True)
     s += emit_glv()

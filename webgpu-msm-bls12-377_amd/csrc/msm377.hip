@@ -117,6 +117,7 @@ struct G1Dev {
   static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // every case is handled inside the formulas
   static __device__ __forceinline__ Pt identity() { return G1::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return G1::madd(a, q, negq); }  // a + q or a - q
+  static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return G1::madd(G1::identity(), q, negq); }  // identity + q: a copy
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return G1::add(a, b); }
   static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
 #pragma unroll
@@ -183,6 +184,7 @@ struct EdDev {
   static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // complete addition law
   static __device__ __forceinline__ Pt identity() { return EdLazy::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return EdLazy::madd_affine(a, q, negq); }
+  static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return EdLazy::madd_affine(EdLazy::identity(), q, negq); }
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return EdLazy::add(a, b); }
   static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
 #pragma unroll
@@ -248,6 +250,7 @@ struct TeDev {
   static __device__ __forceinline__ bool is_bad(const Pt& p) { return Te377::is_bad(p); }
   static __device__ __forceinline__ Pt identity() { return Te377::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Te377::madd(a, q, negq); }
+  static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return Te377::from_base(q, negq); }  // 1 product instead of 8
   static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return Te377::add(a, b); }
   static __device__ __forceinline__ void to_words(const Pt& p, uint32_t* w) {
 #pragma unroll
@@ -304,6 +307,7 @@ struct TeAffBase {
     return p;
   }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Te377::madd_affine(a, q, negq); }
+  static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return Te377::from_base_affine(q, negq); }
 };
 
 // Limb-major bucket array: word j of bucket t of window slot ws at [(ws * PT_WORDS + j) * NB + t].
@@ -879,6 +883,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   // into: the buckets already hold the sums of an earlier chunk of the same MSM (host-buffer entry point, chunked
   // upload): the row's first item continues from there.
   typename CV::Pt acc = (into && it.seg == 0) ? load_bucket<CV>(buckets, ws, t) : CV::identity();
+  bool start_fresh = !(into && it.seg == 0);
   bool bad = false;  // an exceptional pair of the twisted Edwards law (te377.hpp): sticky, the caller falls back
   if (k < end) {
     // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
@@ -896,7 +901,9 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
         nxt = BP::load_base(bases, e_nxt & 0x7fffffffu);
         if (k + 1 < end) e_nn = vi[k + 1];
       }
-      acc = BP::madd(acc, cur, (e_cur >> 31) != 0);
+      // the first entry of a chain that starts from the identity needs no addition (BP::first)
+      acc = start_fresh ? BP::first(cur, (e_cur >> 31) != 0) : BP::madd(acc, cur, (e_cur >> 31) != 0);
+      start_fresh = false;
       bad |= CV::is_bad(acc);
       if (!more) break;
       cur = nxt;

@@ -131,6 +131,28 @@ struct Te377 : TeLazy<Fp, G1Consts> {
     return b;
   }
 
+  // The first addition of a chain, identity + (+-)q, without the 8 products of the general law: the record holds
+  // (Y - X, Y + X, 2d T, 2Z), and (2X : 2Y : 2T : 2Z) is the same projective point -- two additions and ONE product
+  // (2T = (2d T) / d).  Canonical coordinates, as the accumulator invariant asks.
+  static MSM_HD Ext from_base(const PBase& q, bool neg) {
+    Ext r;
+    const El x2 = F::sub(q.ypx, q.ymx), t2 = F::mul(q.kt, F::from_const(K::TE_INV_D));
+    r.x = F::cneg(x2, neg);
+    r.y = F::add(q.ypx, q.ymx);
+    r.t = F::cneg(t2, neg);
+    r.z = q.z2;
+    return r;
+  }
+  static MSM_HD Ext from_base_affine(const ABase& q, bool neg) {  // Z = 1: (2x, 2y, 2dxy / d, 2)
+    Ext r;
+    const El x2 = F::sub(q.ypx, q.ymx), t2 = F::mul(q.kt, F::from_const(K::TE_INV_D));
+    r.x = F::cneg(x2, neg);
+    r.y = F::add(q.ypx, q.ymx);
+    r.t = F::cneg(t2, neg);
+    r.z = F::dbl(F::one());
+    return r;
+  }
+
   // The affine form of the same record: one Fermat inversion per point (~450 field products), affordable only
   // where the table is reused (msm377_g1_set_bases).  bad <=> the map is undefined at this point.
   static MSM_HD ABase affine_from_wire(const uint32_t* x12, const uint32_t* y12, bool& bad) {
