@@ -115,6 +115,7 @@ struct G1Dev {
     return p;
   }
   static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // every case is handled inside the formulas
+  static __device__ __forceinline__ bool is_stored_identity(const Pt& p) { return G1::is_identity(p); }
   static __device__ __forceinline__ Pt identity() { return G1::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return G1::madd(a, q, negq); }  // a + q or a - q
   static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return G1::madd(G1::identity(), q, negq); }  // identity + q: a copy
@@ -182,6 +183,7 @@ struct EdDev {
   }
 
   static __device__ __forceinline__ bool is_bad(const Pt&) { return false; }  // complete addition law
+  static __device__ __forceinline__ bool is_stored_identity(const Pt& p) { return Fq::is_zero(p.x) && Fq::eq(p.y, p.z); }  // (0 : c : 0 : c)
   static __device__ __forceinline__ Pt identity() { return EdLazy::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return EdLazy::madd_affine(a, q, negq); }
   static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return EdLazy::madd_affine(EdLazy::identity(), q, negq); }
@@ -248,6 +250,7 @@ struct TeDev {
     return p;
   }
   static __device__ __forceinline__ bool is_bad(const Pt& p) { return Te377::is_bad(p); }
+  static __device__ __forceinline__ bool is_stored_identity(const Pt& p) { return Fp::is_zero(p.x) && Fp::eq(p.y, p.z); }  // (0 : c : 0 : c), c != 0
   static __device__ __forceinline__ Pt identity() { return Te377::identity(); }
   static __device__ __forceinline__ Pt madd(const Pt& a, const Base& q, bool negq) { return Te377::madd(a, q, negq); }
   static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return Te377::from_base(q, negq); }  // 1 product instead of 8
@@ -1006,7 +1009,11 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
   const uint32_t y = x + half;
   typename CV::Pt a = load_bucket<CV>(buckets, ws, x);
   typename CV::Pt b = load_bucket<CV>(buckets, ws, y);
-  const typename CV::Pt sum = CV::add(a, b);
+  // Empty buckets hold the identity exactly as identity() wrote it (the top window of a 253-bit scalar uses a seventh
+  // of its buckets; small inputs leave most of every window empty): adjacent lanes see adjacent buckets, so whole
+  // waves skip the addition.
+  if (CV::is_stored_identity(b)) return;
+  const typename CV::Pt sum = CV::is_stored_identity(a) ? b : CV::add(a, b);
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_EXCEPTIONAL);
   store_bucket<CV>(buckets, ws, x, sum);
 }
