@@ -17,6 +17,10 @@ N > 1: the 16 window subtasks are sharded over the ranks (rank g owns a contiguo
 windows, no data-path collective), followed by ONE RCCL all-gather of the partial records and
 the Horner combine -- the same 2^20-point problem on more GPUs, so "scaling" is "strong".
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent
+spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before anything has
+touched the GPU (no re-exec of a GPU-initialised process) and relays its output and exit code.
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket accumulation) with
 HIP-event timings taken by the engine on its own stream; `cpu_baseline` times the CPU oracle
 (a port of the reference pipeline, not the reference's WASM) on the same inputs on this host
@@ -38,6 +42,52 @@ NUM_WINDOWS = 16
 NUM_BUCKETS = 32768
 
 
+# Secondary, truly binding roof of the accumulation kernel: 32x32+64-bit multiply-adds.
+# A field product on 13 x 29-bit limbs with 14 reduction steps is 13*13 + 14*12 = 337 v_mad_u64_u32 (csrc/field29.hpp
+# mul_lz); a bucket addition is 8 products with projective base records, 7 with affine ones (csrc/te377.hpp; XYZZ: 10);
+# the chip-wide peak is the microbenchmark figure at 8 waves/SIMD (profiles/microbench_r01.txt: mad64 33605 Gop/s).
+MADS_PER_FIELD_PRODUCT = 13 * 13 + 14 * 12
+MAD_PEAK_GLANEOPS = 33605.0
+
+
+def launch_command(gpus, argv, port):
+    """argv of the child that runs the N ranks: torch.distributed.run on 127.0.0.1 (the container hostname may not
+    resolve), this very script and its own arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 from a plain `python bench.py`: start the ranks as a child process group and relay.  Nothing in
+    this process has initialised HIP at this point (torch is not even imported)."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launch_command(args.gpus, argv, free_port())
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def latest_pmc_summary():
+    """(tag, summary) of the newest committed rocprofv3 PMC summary (profiles/rNN_*/pmc_summary.json)."""
+    prof = os.path.join(ROOT, "profiles")
+    tags = sorted((d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "pmc_summary.json"))), reverse=True) if os.path.isdir(prof) else []
+    for tag in tags:
+        with open(os.path.join(prof, tag, "pmc_summary.json")) as f:
+            return tag, json.load(f)
+    return None, {}
+
+
 def algorithmic_bytes(n, glv=False):
     """B_alg(n) = 32n + 96n + W*96n + 2*W*2^15*144 + 96 (whole MSM), and the
     share of the bucket-accumulation launch: W*96n gathered + W*2^15*144 written.  Behind the GLV front end the
@@ -51,19 +101,18 @@ def algorithmic_bytes(n, glv=False):
 
 
 def pmc_traffic_bytes(log_n):
-    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-    separate passes; FETCH_SIZE doubled per the gfx950 note in /opt/skills/guides/MI355X_MICROARCH.md).  Only valid
-    for the workload the passes were taken on (2^20); None otherwise or when no summary is committed."""
+    """(bytes, source) -- HBM bytes per k_accumulate launch from the newest committed rocprofv3 PMC passes (FETCH_SIZE
+    and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in /opt/skills/guides/MI355X_MICROARCH.md).
+    A STATIC figure from that profile, not a measurement of this run (counters need the profiler); only valid for the
+    workload the passes were taken on (2^20).  (None, None) otherwise."""
     if log_n != 20:
-        return None
-    for tag in ("r01_te",):  # passes taken on the current default path (twisted Edwards form)
-        path = os.path.join(ROOT, "profiles", tag, "pmc_summary.json")
-        if os.path.exists(path):
-            with open(path) as f:
-                k = json.load(f).get("k_accumulate", {})
-            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-                return int((2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-    return None
+        return None, None
+    tag, summary = latest_pmc_summary()
+    k = summary.get("k_accumulate", {})
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        nbytes = int((2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+        return nbytes, "static: profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x2 per the gfx950 note)" % tag
+    return None, None
 
 
 def seeded_scalars(seed, n):
@@ -114,6 +163,7 @@ def side_workload(args, torch, msm, n):
         torch.cuda.synchronize()
         step = lambda: eng.msm_fixed_base_batch_device(d_scalars.data_ptr(), n, batch)  # noqa: E731
         per_step = batch
+        verify_fixed = not args.no_cpu_baseline
         out.update({"metric": "ms per 2^%d fixed-base BLS12-377 G1 MSM (batch of 64, resident bases)" % args.log_n,
                     "dtype": "u32 (29-bit limbs, 64-bit accumulate)",
                     "config": {"workload": "64 x 2^%d fixed-base G1 MSMs over one HBM-resident converted base set, host tail overlapped" % args.log_n}})
@@ -127,6 +177,37 @@ def side_workload(args, torch, msm, n):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / max(1, args.steps) / per_step
     out.update({"value": round(ms, 4), "ms_per_step": round(ms * per_step, 4), "whole_job_hbm_GBps": round(alg / (ms * 1e-3) / 1e9, 2)})
+    if args.workload == "fixed64" and verify_fixed:
+        # Every one of the 64 results against a closed form (after the timed region; the oracle is the checker):
+        # P_i = [a_i]G with a_i = SplitMix64(0x377)_i and scalar set b = the seeded set rotated by b, so
+        # MSM_b = [sum_i k_((i - b) mod n) a_i mod r] G -- one oracle scalar multiplication of the generator each.
+        import ctypes
+
+        import numpy as np
+
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import util
+
+        oracle = util.load_oracle()
+        with np.errstate(over="ignore"):
+            z = np.uint64(0x377) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        a = [int(v) or 1 for v in z.tolist()]
+        ks = [int.from_bytes(scalars_host[32 * i : 32 * i + 32], "little") for i in range(n)]
+        gen = ctypes.create_string_buffer(96)
+        oracle.oracle_g1_generator(ctypes.addressof(gen))
+        import operator
+
+        for b in range(batch):
+            rot = ks[n - b :] + ks[: n - b] if b else ks  # torch.roll(shifts=b): element i of set b is k[(i - b) mod n]
+            total = sum(map(operator.mul, rot, a)) % R_ORDER
+            exp = ctypes.create_string_buffer(96)
+            assert oracle.oracle_g1_scalar_mul(gen.raw, total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
+            if exp.raw != res[b]:
+                raise SystemExit("PARITY FAILURE: fixed-base MSM %d of the batch differs from the closed form" % b)
+        out["verified"] = "all %d results bit-exact against the closed form [sum_i k_i a_i]G (oracle scalar multiplication)" % batch
     if args.workload == "ed" and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import util
@@ -167,6 +248,8 @@ def main():
         "fixed64 = configs[4] 64 fixed-base MSMs over one HBM-resident base set (informational lines, single GPU)",
     )
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import torch
 
@@ -222,10 +305,13 @@ def main():
     glv_single = world == 1 and not te_single and os.environ.get("MSM377_GLV", "0") == "1"
     sharder = ShardedMsm(rank, world, device=xdev)
     sharder_glv = ShardedMsm(rank, world, device=xdev, num_windows=8) if use_glv else None
+    resident = world > 1 and backend == "nccl" and not use_glv  # records stay in HBM until the all-gather
 
     def step():
         if world == 1:
             return eng.msm_device(pp, sp, n)
+        if resident:
+            return sharder.run_resident(lambda b, c, out_ptr: eng.window_partials_resident(pp, sp, n, b, c, out_ptr), eng.combine_partials)
         if use_glv:
             try:
                 return sharder_glv.run(lambda b, c: eng.glv_window_partials_device(pp, sp, n, b, c))
@@ -270,6 +356,12 @@ def main():
         acc_ms = stages.get("accumulate_kernel", 0.0)  # HIP events around the k_accumulate launch alone
         acc_bytes_launch = acc_bytes * my_windows / nwin  # one launch covers this rank's share of the windows
         achieved = acc_bytes_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        traffic, traffic_source = pmc_traffic_bytes(args.log_n) if world == 1 else (None, None)
+        # int32-mad roof: one launch adds every non-zero digit's point once (16 n additions less the 2^-16 share of
+        # zero digits: negligible, not subtracted) at `products` field products of 337 multiply-adds each
+        products = eng.accumulate_products()
+        lane_mads = NUM_WINDOWS * n * my_windows / nwin * products * MADS_PER_FIELD_PRODUCT
+        mad_rate = lane_mads / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         out = {
             "metric": "ms per 2^%d BLS12-377 G1 MSM" % args.log_n,
             "value": round(ms_per_step, 4),
@@ -298,10 +390,21 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": pmc_traffic_bytes(args.log_n) if world == 1 else None,
-                "traffic_source": "profiles/*/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x2 per the gfx950 note)",
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(acc_bytes_launch),
                 "kernel_ms": round(acc_ms, 4),
+                # the roof that actually binds this kernel: 32x32+64-bit multiply-adds (v_mad_u64_u32), not bytes
+                "secondary": {
+                    "bound": "int32-mad",
+                    "achieved": round(mad_rate, 1),
+                    "peak": MAD_PEAK_GLANEOPS,
+                    "unit": "G lane-mad/s",
+                    "frac": round(mad_rate / MAD_PEAK_GLANEOPS, 4),
+                    "lane_mads_per_launch": int(lane_mads),
+                    "derivation": "%d windows x n additions x %d field products x %d v_mad_u64_u32 (13x13 + 14x12, csrc/field29.hpp); peak = mad64 at 8 waves/SIMD, profiles/microbench_r01.txt"
+                    % (my_windows, products, MADS_PER_FIELD_PRODUCT),
+                },
             },
             "whole_job_hbm_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 2),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},

@@ -38,6 +38,10 @@ extern "C" {
 #define MSM377_ENOMEM (-4)    /* device or host allocation failed */
 #define MSM377_ESTATE (-5)    /* call sequence error (e.g. fixed-base MSM before set_bases) */
 #define MSM377_EGLVRANGE (-6) /* GLV window sharding only: a scalar >~ 2^254; repeat with the plain window path */
+#define MSM377_EEXCEPTIONAL (-7) /* combine of window records only: the twisted-Edwards records add up to an exceptional
+                                    case of their (incomplete) addition law -- possible only with input points outside the
+                                    prime-order subgroup; recompute the windows in form 0 (msm377_ctx_set_g1_form) and combine
+                                    again.  The full-MSM entry points handle this themselves and never return it. */
 
 #define MSM377_NUM_WINDOWS 16          /* ceil(256 / 16): submission.ts:108-109 */
 #define MSM377_WINDOW_BITS 16          /* chunk_size for n >= 2^16: submission.ts:97 */
@@ -94,6 +98,11 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
  * mixture, so ranks never have to agree on a form. */
 int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n,
                                      uint32_t win_begin, uint32_t win_count, uint8_t* partials_out);
+/* The same, but the records are left in DEVICE memory (d_partials_out: win_count records, 16-byte aligned): the
+ * exchange of a multi-GPU run (one RCCL all-gather over xGMI) reads them where they are, no host round trip.
+ * Returns with the context's stream idle, so any other stream may consume the buffer. */
+int msm377_g1_window_partials_resident(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n,
+                                       uint32_t win_begin, uint32_t win_count, void* d_partials_out);
 /* Optional, before the exchange: a rank folds the records of its own win_count CONSECUTIVE windows (in place,
  * same size, same total: one short Horner chain over them; every point but one becomes the identity), which
  * leaves the final combine on every rank with its doublings and one addition per rank instead of 16 per
@@ -103,6 +112,8 @@ int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count);
  * the ranks) into the final affine result: Horner over the windows, one field inversion.
  * Host-only; needs no context and no device (replaces the CPU tail, submission.ts:290-321). */
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
+/* The same on the context's tail threads (four Horner chains, as inside msm377_g1_msm): 0.12 instead of 0.18 ms. */
+int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uint8_t out_xy[96]);
 
 /* The same sharding behind the GLV front end (opt-in, prime-order subgroup points only -- see
  * msm377_ctx_set_glv; Weierstrass form): MSM377_GLV_WINDOWS = 8 windows over {P_i, phi(P_i)};
@@ -142,7 +153,14 @@ int msm377_ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, 
  *   val_idx  n u32          point index | (sign << 31), grouped by key
  *   buckets  32768 x 52 u32 bucket t = 1..32768 at row t-1: X, Y, ZZ, ZZZ (13 Montgomery words
  *                           each) as left by bucket accumulation
- * Only valid when the context was created with stage capture enabled. */
+ * Only valid when the context was created with stage capture enabled.
+ *
+ * The bucket words describe the coordinate system the call ended in (msm377_ctx_get_stage_form): XYZZ as above for
+ * form 0 and for calls that fell back to it, (X, Y, T, Z) extended twisted Edwards coordinates (csrc/te377.hpp: lazy
+ * residues below p + 2^354, the identity stored as (0, c, 0, c)) for the default form. */
+#define MSM377_STAGE_FORM_XYZZ 0
+#define MSM377_STAGE_FORM_TE 1
+int msm377_ctx_get_stage_form(const msm377_ctx* ctx); /* -1: nothing captured */
 int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled);
 int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint32_t* row_ptr, uint32_t* val_idx, uint32_t* buckets);
 /* Convert one Montgomery XYZZ point (52 words) to the affine wire format (host-only). */
@@ -164,6 +182,16 @@ int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
  * the window-partials entry points always use it. */
 int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form);
 
+/* How often this context had to rerun (part of) a call on the Weierstrass path because the twisted Edwards form hit
+ * an exceptional case of its addition law, and where the last one surfaced (MSM377_FB_* bits).  Zero for inputs in
+ * the prime-order subgroup; the parity tests use it to prove that each check fires. */
+#define MSM377_FB_ACCUMULATE 4  /* a bucket addition in k_accumulate */
+#define MSM377_FB_MERGE 8       /* the merge of a split row's partial sums */
+#define MSM377_FB_TREE 16       /* a bucket-reduction level */
+#define MSM377_FB_TAIL 32       /* the host tail (Horner over the partial records) */
+#define MSM377_FB_CONVERT 64    /* an input point the Edwards model cannot represent (order 2 or 4) */
+int msm377_ctx_get_fallback_info(const msm377_ctx* ctx, uint64_t* count, uint32_t* last_mask);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 #define MSM377_STAGE_CONVERT 0     /* points -> Montgomery records */
@@ -180,6 +208,9 @@ int msm377_ctx_set_timing(msm377_ctx* ctx, int enabled);
 /* Durations in milliseconds of the last call's stages (MSM377_NUM_STAGES entries; the TAIL
  * entry is host wall time). */
 int msm377_ctx_get_stage_ms(msm377_ctx* ctx, double* ms_out);
+/* Field products per bucket addition of the last accumulation launch (10 Weierstrass XYZZ, 8 twisted Edwards with
+ * projective base records, 7 with affine ones): bench.py prices the int32 multiply-add roof with it. */
+int msm377_ctx_get_products_per_addition(const msm377_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -11,42 +11,7 @@ import ctypes
 import pyref as R
 import util
 
-MULTIPLY = [
-    ((8257472440026412470855823161360599835763884965512266031735196605946124540781, 1317236406994089734712440120087390006881665376441526398782786543205559959784),
-     1547425874856602534767534308429521876318647158746421300258127830068083829107,
-     (280707319831642431009504151884114731107732475984662874186498832708556594042, 6780405324232516243853088596794063648880273989664802391241817504589639452676)),
-    ((4145103444972959370752799658138366514606148292573847443656295656764663256852, 8195192268960871257765559104440454785805900892679487766705407419363540677979),
-     1714738424968869845390842595910648313891392225738655712285792046986013878987,
-     (2877000835025694110737495937937857548250497144965509405668304930059046899074, 1584375919144210261376433026300851516663764194894843872483164392123867734886)),
-    ((1407393795595197158321967850589923407460177064783512277145169077414223929519, 7432153702653035036383775355082339546086624529603034704124264595653244652944),
-     1714738424968869845390842595910648313891392225738655712285792046986013878987,
-     (6812460234826301275802420261414545657179156735634459146286228208874069968311, 5903077177443029880600616769227903613786094864399302847410393125625806571974)),
-    ((2852308072744418503022691767087648768127882203872961492947930316205537975830, 4276917318468280744562416198969583201366895049007434396046151895529617346724),
-     885681279335589295694233278030888423770570959635027694177964832914872649115,
-     (3610365899681714779827737389912654352565069132637355828354779992034131153624, 7759939422231982859892322839012756195668494835579501312737965937667499450944)),
-    ((4899983337726338278640781704713890341229795000554597192096411729290172809762, 6490912106011982932993118483094030962453896277891374577826843372689626084690),
-     2096750020814833916645641418924654152172414459208956903895628626218487785794,
-     (4642589023830411184277633193203785345703779976699830339808322679184563884257, 7784411079693722795119796948076918321132943145855328972555180815499881182349)),
-]
-POINT_FROM_X = [
-    (7277225673954309719883819123615758925677189693308296529054933534083481597875, 1534757228766746657952411535957375215012967279942781097930718794729416379764),
-    (6668401193057322520970952572257172131583278070174751616942722086839745568612, 2451637686636076672169141722855773330775606040023439333435865738274264590089),
-    (5171864189979210424267942198699979498834100132989590478023237401362416394215, 771623517164978762318496098769994406685190221055386234983870046878237368347),
-    (4073685905190079830563316481255126820231714757721080083250562600230098465667, 7724497955715594404046701658091914148102455176621137343342321340099935318344),
-    (5607146324525996389057348716233686669891151387820192320410858992272460798043, 7140300045010707491219668027665480921808083167278591679994462390519123119286),
-    (8290126653874599468882190194081316363779752818921027324794763746032839143130, 5650187918377417409124091323871667504886558718947019752893838402231728068795),
-]
-ADD_GROUPS = [
-    (8172491321683091888948767720126491291334498151367935174834739919916587902885, 6398616098668069932591809496969092508189703886845851538529306481398791254505, 6098884730637101648176576569680682097727731315679939226583145374341012652933),
-    (5265081760859433483133294014934052209218999610322594178767498019044206417582, 2063000405888842163751349173523051445370584893047038564267648437120577005175, 6476202634512227671235877046929344087427366950393375000521665681337155323321),
-    (2267804453849548326441105932178046088516965666196959520730613219383769450836, 4407911307578806921901458939347649080208231626630832716981525978619048166152, 5786258225753402907650271726047597104252057332301870339194408122376703625189),
-    (4644020117506100108114238681686210885380126709522154112824613061426159571896, 4644020117506100108114238681686210885380126709522154112824613061426159571896, 4368133022969454257850374558672411800299209285195778089440085290555701516667),
-    (7567318425042049695485063481352884626263173541493743764753928133860027560480, 7567318425042049695485063481352884626263173541493743764753928133860027560480, 5042473777803417606579440401406822102329732371743950988738806767808616709467),
-]
-GROUP_SCALAR_MUL = [
-    (4541840636887708036714559817495407429189575168354480822933150714442012162643, 125325161507509325346578589838941278533045954469449950613276078176224054210, 6444119914335573715335918680414238993802948789453145346737287055543838829565),
-    (2796670805570508460920584878396618987767121022598342527208237783066948667246, 1753533570350686550323082834194063544688355123444645930667634514069517491627, 5324992470787461040823919570440348586607207885188029730405305593254964962313),
-]
+from ed_vectors import ADD_GROUPS, GROUP_SCALAR_MUL, MULTIPLY, POINT_FROM_X  # the reference-held vectors (data)
 
 
 def o_mul(oracle, pt, k):

@@ -9,6 +9,7 @@ import pytest
 import pyref as R
 import util
 import webgpu_msm_bls12_377_amd as msm
+from ed_vectors import ADD_GROUPS, GROUP_SCALAR_MUL, MULTIPLY
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +24,64 @@ def test_golden_vectors(engine, golden):
     for name, case in golden.items():
         if name.startswith("ed_"):
             assert engine.ed_msm(case["points"], case["scalars"]) == case["expected"], name
+
+
+# ---- the reference's own Edwards vectors through the HIP path (n = 1 and n = 2 MSMs in disguise) ----
+# Expected values are the reference's published answers, not the oracle's: this is what pins the GPU path to the
+# reference for this curve (missing #1).
+
+
+def _xy(buf: bytes):
+    return (int.from_bytes(buf[:32], "little"), int.from_bytes(buf[32:], "little"))
+
+
+@pytest.mark.parametrize("case", range(len(MULTIPLY)))
+def test_reference_multiply_vectors_as_one_point_msm(engine, case):
+    """src/reference/utils/FieldMath.test.ts:4-62: [k]P as the MSM of one point, host and device entry points."""
+    pt, k, exp = MULTIPLY[case]
+    pts, ks = R.ed_encode_points([pt]), R.encode_scalars([k])
+    assert _xy(engine.ed_msm(pts, ks)) == exp
+    d_p, d_s = dev(pts), dev(ks)
+    assert _xy(engine.ed_msm_device(d_p.data_ptr(), d_s.data_ptr(), 1)) == exp
+
+
+def test_reference_multiply_vectors_as_one_composite_msm(engine):
+    """All five MULTIPLY pairs in ONE MSM: the expectation is the sum (pure Python, complete affine law) of the
+    five answers the reference publishes -- no oracle involved."""
+    pts = R.ed_encode_points([pt for pt, _, _ in MULTIPLY])
+    ks = R.encode_scalars([k for _, k, _ in MULTIPLY])
+    exp = R.ED_ID
+    for _, _, res in MULTIPLY:
+        exp = R.ed_add(exp, res)
+    assert _xy(engine.ed_msm(pts, ks)) == exp
+    # ... and each pair repeated in 40 copies with the scalar split into 40 random shares (fills real buckets)
+    rnd = random.Random(5)
+    big_pts, big_ks = [], []
+    for pt, k, _ in MULTIPLY:
+        shares = [rnd.randrange(R.ED_SUBGROUP) for _ in range(39)]
+        shares.append((k - sum(shares)) % R.ED_SUBGROUP)
+        big_pts += [pt] * 40
+        big_ks += shares
+    assert _xy(engine.ed_msm(R.ed_encode_points(big_pts), R.encode_scalars(big_ks))) == exp
+
+
+@pytest.mark.parametrize("case", range(len(ADD_GROUPS)))
+def test_reference_add_groups_vectors_as_two_point_msm(engine, case):
+    """src/reference/utils/wasmFunctions.test.ts:24-36: P1 + P2 as the MSM with scalars (1, 1).  The reference's
+    "group" strings carry x only; y comes from the decompression the reference pins in FieldMath.test.ts:64-98
+    (tests/test_ed_oracle_pins.py::test_fieldmath_point_from_x_vectors).  Cases 3 and 4 are doublings (P1 = P2)."""
+    x1, x2, x3 = ADD_GROUPS[case]
+    a, b = R.ed_point_from_x(x1), R.ed_point_from_x(x2)
+    got = _xy(engine.ed_msm(R.ed_encode_points([a, b]), R.encode_scalars([1, 1])))
+    assert got[0] == x3 and R.ed_on_curve(got)
+
+
+@pytest.mark.parametrize("case", range(len(GROUP_SCALAR_MUL)))
+def test_reference_group_scalar_mul_vectors_as_one_point_msm(engine, case):
+    """src/reference/utils/wasmFunctions.test.ts:38-49."""
+    x, k, xr = GROUP_SCALAR_MUL[case]
+    got = _xy(engine.ed_msm(R.ed_encode_points([R.ed_point_from_x(x)]), R.encode_scalars([k])))
+    assert got[0] == xr and R.ed_on_curve(got)
 
 
 def test_empty_input_is_the_neutral_element(engine):

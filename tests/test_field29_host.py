@@ -214,7 +214,29 @@ def test_twisted_edwards_exceptional_inputs_are_flagged(shim):
     qpt = R.add(p, two_torsion)
     q = (ctypes.c_uint32 * 48)(*(list(xy24(p)) + list(xy24(qpt))))
     bad = shim.shim_te_sum(q, (ctypes.c_uint8 * 2)(0, 1), 2, 1, 0, out, ext)
-    assert bad == 1 or out.raw == R.encode_result(two_torsion)
+    assert bad == 1 or out.raw == R.encode_result(two_torsion)  # T2 = (-1, 0) is a finite point of the model: not exceptional
+    # T' = (-omega, 0), the 2-torsion point the model sends to infinity: conversion flags T' itself, and P, P + T' are
+    # an exceptional pair under BOTH signs -- the flag must be raised by the addition (is_bad), in a plain chain
+    # (k_accumulate) and when the pair meets as partial sums of a general addition (merge / tree levels).
+    tp = util.t_prime()
+    assert shim.shim_te_sum(xy24(tp), (ctypes.c_uint8 * 1)(0), 1, 1, 0, out, ext) == 1
+    qt = R.add(p, tp)
+    assert R.on_curve(qt)
+    q = (ctypes.c_uint32 * 48)(*(list(xy24(p)) + list(xy24(qt))))
+    for negs in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        assert shim.shim_te_sum(q, (ctypes.c_uint8 * 2)(*negs), 2, 1, 0, out, ext) == 1, negs  # chain: P then +-(P + T')
+        assert shim.shim_te_sum(q, (ctypes.c_uint8 * 2)(*negs), 2, 2, 0, out, ext) == 1, negs  # two partial sums, general add
+    assert shim.shim_te_sum_affine(q, (ctypes.c_uint8 * 2)(0, 0), 2, out) == 1  # affine records (7-product additions)
+    # three points where only the LAST addition is exceptional: (P + R) + (P + R + T')
+    r2 = R.mul(R.G, 999)
+    q3 = (ctypes.c_uint32 * 72)(*(list(xy24(p)) + list(xy24(r2)) + list(xy24(R.add(R.add(p, r2), tp)))))
+    assert shim.shim_te_sum(q3, (ctypes.c_uint8 * 3)(0, 0, 0), 3, 1, 0, out, ext) == 1
+    # ... and a non-exceptional sum over the same kind of points stays exact
+    q3b = (ctypes.c_uint32 * 72)(*(list(xy24(p)) + list(xy24(qt)) + list(xy24(r2))))
+    assert shim.shim_te_sum(q3b, (ctypes.c_uint8 * 3)(0, 0, 0), 3, 3, 0, out, ext) in (0, 1)
+    q2 = (ctypes.c_uint32 * 48)(*(list(xy24(r2)) + list(xy24(qt))))
+    assert shim.shim_te_sum(q2, (ctypes.c_uint8 * 2)(0, 0), 2, 1, 0, out, ext) == 0
+    assert out.raw == R.encode_result(R.add(r2, qt))
 
 
 def test_lazy_bounds_proof():

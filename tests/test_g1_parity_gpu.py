@@ -123,6 +123,127 @@ def test_stage_parity(engine, oracle):
         engine.set_g1_form("edwards")
 
 
+def test_stage_parity_edwards_form(engine, oracle):
+    """The DEFAULT accumulation kernel (k_accumulate<TeDev>, twisted Edwards buckets) bucket by bucket against the
+    oracle's SMVP (WGSL semantics, smvp_bls12_377.template.wgsl:72-160): the read-back returns the (X, Y, T, Z)
+    words, decoded here with Python integers (extended-coordinate invariant and curve equation checked on the way)."""
+    n = 5000
+    pts, ks = seeded_inputs(oracle, n, 4343)
+    engine.set_stage_capture(True)
+    default_path(engine)
+    try:
+        assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+        assert engine.stage_form() == 1  # twisted Edwards, no fallback happened
+        for slot in (0, 9, 15):
+            bk = engine.read_stage(slot, n, want=("buckets",))["buckets"]
+            bo = ctypes.create_string_buffer(96 * 32768)
+            assert oracle.oracle_g1_smvp_window(pts, ks, n, 16, slot, ctypes.addressof(bo)) == 0
+            nonempty = 0
+            for t in range(1, 32769):
+                exp = bo.raw[96 * (t % 32768) : 96 * (t % 32768) + 96]
+                words = bk[t - 1]
+                if not words[0:13].any() and np.array_equal(words[13:26], words[39:52]):  # (0 : c : 0 : c): the identity
+                    assert exp == R.encode_result(None), (slot, t)
+                    continue
+                nonempty += 1
+                if nonempty <= 300:
+                    assert R.encode_result(util.affine_from_te_ext_words(words)) == exp, (slot, t)
+            assert nonempty > (1000 if slot < 15 else 500)
+    finally:
+        engine.set_stage_capture(False)
+
+
+def test_every_check_of_the_edwards_law_fires(engine):
+    """the exceptional pairs of the a = -1 law are P, P + T' with T' = (-omega, 0) (util.t_prime) -- NOT the
+    2-torsion point (-1, 0) the older tests used, whose Edwards image is an ordinary point.  One case per place the
+    pair can meet: a bucket chain in k_accumulate, the merge of a split row, a thread-level and a quad-level step of
+    the bucket reduction, and the host tail.  Each must (a) raise its flag -- read back through
+    msm377_ctx_get_fallback_info -- and (b) still return the exact sum, computed here with Python integers."""
+    from webgpu_msm_bls12_377_amd.host.engine import FB_ACCUMULATE, FB_MERGE, FB_TAIL, FB_TREE
+
+    tp = util.t_prime()
+    p = R.mul(R.G, 31337)
+    q = R.add(p, tp)
+    assert R.on_curve(q)
+    c = R.mul(R.G, 777)
+    a = R.add(R.mul(c, 1 << 16), tp)
+    cases = [
+        # same digit, same bucket: first(P) then madd(P + T')
+        ("accumulate", [p, q], [5, 5], FB_ACCUMULATE),
+        # opposite signs of one digit meet in the same row as well: 65527 = -9 + 2^16, so window 0 holds P - (P + T')
+        ("accumulate, opposite signs", [p, q], [9, 65527], FB_ACCUMULATE),
+        # one row of 32 entries = two work items of 16 (SEG_MIN): partial sums 16 P and 16 P + T' whatever the order
+        ("split-row merge", [p] * 31 + [q], [3] * 32, FB_ACCUMULATE | FB_MERGE),
+        # buckets 0 and 16384 of window 0 meet at reduction level 0 (one thread per addition)
+        ("tree level 0", [p, q], [1, 16385], FB_TREE),
+        # buckets 0 and 16 meet at level 10 (one lane quad per addition)
+        ("tree level 10", [p, q], [1, 17], FB_TREE),
+        # windows 1 and 0 meet in the host's Horner chain: [2^16] C + ([2^16] C + T')
+        ("host tail", [c, a], [1 << 16, 1], FB_TAIL),
+    ]
+    default_path(engine)
+    for name, pts, ks, where in cases:
+        exp = R.encode_result(R.msm_naive(pts, ks))
+        pb, sb = R.encode_points(pts), R.encode_scalars(ks)
+        n = len(pts)
+        before, _ = engine.fallback_info()
+        assert engine.msm(pb, sb) == exp, name
+        count, mask = engine.fallback_info()
+        assert count == before + 1 and mask & where, (name, count - before, mask)
+        # device entry point, resident table (projective or affine records), batch
+        d_p, d_s = dev(pb), dev(sb + sb)
+        assert engine.msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == exp, name
+        engine.set_bases(pb)
+        before, _ = engine.fallback_info()
+        assert engine.msm_fixed_base(sb) == exp, name
+        assert engine.fallback_info()[0] == before + 1, name
+        assert engine.msm_fixed_base(sb) == exp, name  # the table stays in the form it fell back to
+        assert engine.fallback_info()[0] == before + 1, name
+        engine.set_bases(pb)
+        assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 2) == [exp, exp], name
+        # window shards: the shard that owns the pair reruns alone (untagged records); a pair that only meets in the
+        # tail is reported by the combine, and form 0 records combine to the right point
+        parts = [engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, *msm.windows_for_rank(r, 4)) for r in range(4)]
+        if where == FB_TAIL:
+            with pytest.raises(msm.MsmError) as e:
+                msm.combine_partials(b"".join(parts))
+            assert e.value.code == -7
+            with pytest.raises(msm.MsmError) as e:
+                engine.combine_partials(b"".join(parts))
+            assert e.value.code == -7
+            engine.set_g1_form("weierstrass")
+            try:
+                parts = [engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, *msm.windows_for_rank(r, 4)) for r in range(4)]
+            finally:
+                default_path(engine)
+        assert msm.combine_partials(b"".join(parts)) == exp, name
+        assert engine.combine_partials(b"".join(parts)) == exp, name
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_window_records_left_in_device_memory(engine, oracle, world):
+    """The RCCL path of bench.py --gpus N: msm377_g1_window_partials_resident leaves a rank's records in HBM (what the
+    all-gather reads), bit-identical to the host-buffer variant; the context-threaded combine gives the oracle's result."""
+    import torch
+
+    n = 3000
+    pts, ks = seeded_inputs(oracle, n, 123 + world)
+    d_p, d_s = dev(pts), dev(ks)
+    from webgpu_msm_bls12_377_amd.host.engine import WINDOW_PARTIAL_BYTES
+
+    gathered = torch.zeros(16 * WINDOW_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    off = 0
+    for r in range(world):
+        b, c = msm.windows_for_rank(r, world)
+        engine.window_partials_resident(d_p.data_ptr(), d_s.data_ptr(), n, b, c, gathered.data_ptr() + off)
+        host = engine.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, b, c)
+        assert gathered[off : off + c * WINDOW_PARTIAL_BYTES].cpu().numpy().tobytes() == host
+        off += c * WINDOW_PARTIAL_BYTES
+    rec = gathered.cpu().numpy().tobytes()
+    exp = util.oracle_msm(oracle, pts, ks)
+    assert engine.combine_partials(rec) == exp == msm.combine_partials(rec)
+
+
 def select_path(engine, path):
     """The three internal paths of the G1 entry points: twisted Edwards form (default), Weierstrass XYZZ behind the
     GLV front end, Weierstrass XYZZ with the plain 16 windows."""

@@ -100,3 +100,36 @@ def test_combine_accepts_mixed_record_forms_and_folded_blocks():
                 assert len(mine) == c * WINDOW_PARTIAL_BYTES
                 folded.append(mine)
             assert msm.combine_partials(b"".join(folded)) == exp, (pattern, world)
+
+
+def test_edwards_tail_reports_exceptional_cases():
+    """ADVICE r01 (fp64_host.hpp): the a = -1 law is not complete on this curve, and the host tail used to add without
+    looking: C with scalar 2^16 and A = [2^16]C + T' with scalar 1 (T' = (-omega, 0), util.t_prime) make the Horner step
+    [2^16]C + A exceptional (Z3 = 0) although the true sum is an ordinary point.  Every add / dbl of the tail now checks:
+    the combine entry points return MSM377_EEXCEPTIONAL, the optional fold leaves its records alone, and the same
+    records in Weierstrass form combine to the right point."""
+    from webgpu_msm_bls12_377_amd.host.engine import EEXCEPTIONAL, fold_partials_bytes
+
+    rnd = random.Random(21)
+    tp = util.t_prime()
+    c = R.mul(R.G, 777)
+    a = R.add(R.mul(c, 1 << 16), tp)
+    assert R.on_curve(a)
+    win = [[None] * 16 for _ in range(16)]
+    win[0][0], win[1][0] = a, c
+    expect = R.encode_result(R.add(a, R.mul(c, 1 << 16)))
+    te = b"".join(te_record(win[w], rnd) for w in range(16))
+    with pytest.raises(msm.MsmError) as e:
+        msm.combine_partials(te)
+    assert e.value.code == EEXCEPTIONAL
+    # the pair in two windows of one rank: folding would hit the same case, so the records stay as they are
+    assert fold_partials_bytes(te[: 2 * E.WINDOW_PARTIAL_BYTES]) == te[: 2 * E.WINDOW_PARTIAL_BYTES]
+    # mixed forms: the Edwards chain alone is still exceptional
+    mixed = b"".join(te_record(win[w], rnd) if w < 2 else record(win[w], rnd) for w in range(16))
+    with pytest.raises(msm.MsmError) as e:
+        msm.combine_partials(mixed)
+    assert e.value.code == EEXCEPTIONAL
+    # one of the two in Weierstrass form: the chains no longer meet inside the Edwards law
+    split = b"".join(record(win[w], rnd) if w == 0 else te_record(win[w], rnd) for w in range(16))
+    assert msm.combine_partials(split) == expect
+    assert msm.combine_partials(b"".join(record(win[w], rnd) for w in range(16))) == expect

@@ -35,3 +35,4 @@ def test_compute_msm_js(golden, name):
     assert got["x"] == str(ex) and got["y"] == str(ey)
     assert got["empty_x"] == "0" and got["empty_y"] == "1"  # submission.ts:93-95
     assert got["version"].startswith("msm377")
+    assert got["forms"] == 3  # Buffer, BigIntPoint[] / bigint[] and U32ArrayPoint[] / Uint32Array[] all went through the addon and agreed

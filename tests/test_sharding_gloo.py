@@ -2,8 +2,11 @@
 host combine.  The per-rank window work is done by the ORACLE here (no GPU in
 this container); on the GPU box the same sharded_msm() is driven by MsmEngine.window_partials_device
 (tests/test_g1_parity_gpu.py, bench.py).  CPU only."""
+import ctypes
 import os
+import random
 import socket
+import struct
 import sys
 
 import pytest
@@ -48,7 +51,14 @@ def _worker(rank, world, port, case_name, q):
         sh = ShardedMsm(rank, world, device="cpu")
         out2 = sh.run(partials_fn)
         out3 = sh.run(partials_fn)  # buffers are reusable
-        q.put((rank, out == case["expected"] and out2 == out and out3 == out))
+
+        # the RCCL-path shape (records written straight into the exchange buffer, all-gather, one read-back, combine)
+        def write_records(begin, count, d_out):
+            data = partials_fn(begin, count)
+            ctypes.memmove(d_out, data, len(data))
+
+        out4 = sh.run_resident(write_records)
+        q.put((rank, out == case["expected"] and out2 == out and out3 == out and out4 == out))
     finally:
         dist.destroy_process_group()
 
@@ -85,3 +95,62 @@ def test_single_rank_needs_no_process_group(oracle, golden):
     _, ws = util.oracle_msm_params(oracle, case["points"], case["scalars"], 16, 256, want_windows=True)
     out = sharded_msm(lambda b, c: b"".join(util.partial_record_from_window_sum(R.decode_result(ws[96 * w : 96 * w + 96])) for w in range(b, b + c)), 0, 1)
     assert out == case["expected"]
+
+
+def _exceptional_worker(rank, world, port, q):
+    """Edwards records that add up to an exceptional case of their law (tests/test_host_tail.py): every rank's combine
+    reports it, every rank recomputes its windows in Weierstrass form, the second exchange succeeds."""
+    import pyref as R
+    import torch.distributed as dist
+    from webgpu_msm_bls12_377_amd.host.sharding import ShardedMsm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rnd = random.Random(5)
+        c = R.mul(R.G, 4242)
+        a = R.add(R.mul(c, 1 << 16), util.t_prime())
+        win = [[None] * 16 for _ in range(16)]
+        win[0][0], win[1][0] = a, c
+        calls = []
+
+        def pack(words):
+            return struct.pack("<%dI" % len(words), *words)
+
+        def edwards(begin, count, d_out):
+            calls.append("edwards")
+            data = b"".join(pack(sum((util.te_record_point_words(p, rnd.randrange(1, R.P), tag=(i == 0)) for i, p in enumerate(win[w])), [])) for w in range(begin, begin + count))
+            ctypes.memmove(d_out, data, len(data))
+
+        def weierstrass(begin, count, d_out):
+            calls.append("weierstrass")
+            data = b"".join(pack(sum((util.record_point_words(p, rnd.randrange(1, R.P)) for p in win[w]), [])) for w in range(begin, begin + count))
+            ctypes.memmove(d_out, data, len(data))
+
+        sh = ShardedMsm(rank, world, device="cpu")
+        out = sh.run_resident(edwards, rerun_weierstrass=weierstrass)
+        ok = out == R.encode_result(R.add(a, R.mul(c, 1 << 16))) and calls == ["edwards", "weierstrass"]
+        try:
+            sh.run_resident(edwards)  # no way to recompute: the error surfaces
+            ok = False
+        except msm.MsmError as e:
+            ok = ok and e.code == -7
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exceptional_records_are_recomputed_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_exceptional_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]

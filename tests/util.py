@@ -168,6 +168,20 @@ def te_params():
     return _TE
 
 
+def t_prime():
+    """A 2-torsion point of y^2 = x^3 + 1 OTHER than (-1, 0): (-omega, 0) with omega a primitive cube root of unity.
+    The twisted Edwards model (built on (-1, 0)) sends it to a point at infinity, so P and P + T' are an exceptional
+    pair of the a = -1 addition law (csrc/te377.hpp): P + (P + T') and P - (P + T') both come out with Z3 = 0."""
+    g = 2
+    while pow(g, (R.P - 1) // 3, R.P) == 1:
+        g += 1
+    omega = pow(g, (R.P - 1) // 3, R.P)
+    assert omega != 1 and pow(omega, 3, R.P) == 1
+    pt = ((-omega) % R.P, 0)
+    assert R.on_curve(pt) and R.add(pt, pt) is None
+    return pt
+
+
 def te_record_point_words(pt, z=1, tag=False):
     """Weierstrass affine point (or None) -> one twisted Edwards partial-record point (X, Y, T, Z as 12 u32 words each,
     radix-2^384 Montgomery form), scaled by a projective factor z; tag sets the record's coordinate-system bit."""
@@ -192,6 +206,23 @@ def affine_from_te_record_words(words):
     w = [int(x) for x in words]
     w[11] &= 0x7FFFFFFF  # the record's coordinate-system tag (fp64_host.hpp TE_RECORD_TAG)
     X, Y, T, Z = (sum(w[12 * c + i] << (32 * i) for i in range(12)) * ri % R.P for c in range(4))
+    assert Z != 0 and (X * Y - T * Z) % R.P == 0, "extended-coordinate invariant T Z = X Y violated"
+    te = te_params()
+    zi = pow(Z, -1, R.P)
+    xe, ye = X * zi % R.P, Y * zi % R.P
+    assert (-xe * xe + ye * ye - 1 - te["d"] * xe * xe * ye * ye) % R.P == 0, "not on the Edwards curve"
+    if xe == 0:
+        return None if ye == 1 else (R.P - 1, 0)
+    u = (1 + ye) * pow(1 - ye, -1, R.P) % R.P
+    v = te["c"] * u * pow(xe, -1, R.P) % R.P
+    si = pow(te["s"], -1, R.P)
+    return ((u * si - 1) % R.P, v * si % R.P)
+
+
+def affine_from_te_ext_words(words):
+    """A twisted Edwards BUCKET in the device format (X, Y, T, Z: 13 x 29-bit limbs each, Montgomery radix 2^406, lazy
+    residues; csrc/te377.hpp) -> Weierstrass affine point via Python ints (None for the identity)."""
+    X, Y, T, Z = (from_limbs29_mont(words[13 * c : 13 * c + 13]) for c in range(4))
     assert Z != 0 and (X * Y - T * Z) % R.P == 0, "extended-coordinate invariant T Z = X Y violated"
     te = te_params()
     zi = pow(Z, -1, R.P)

@@ -306,23 +306,53 @@ inline void teh_to_wire(const TeH::Ext& p, uint8_t out[96]) {
   Fp64::to_wire(x, out);
   Fp64::to_wire(y, out + 48);
 }
+// The a = -1 law on this curve is NOT complete (d is a square, te377.hpp): an addition or doubling whose true
+// result is one of the points at infinity of the Edwards model comes out with Z3 = 0, and a later operation can
+// lead back to Z != 0 with a wrong value.  The GPU kernels check every addition; so does the tail: every add / dbl
+// below reports Z3 = 0 through the sticky flag and the caller reruns on the Weierstrass path.  (Inside the
+// prime-order subgroup this never fires.)
+struct TeChecked {
+  bool bad = false;
+  TeH::Ext add(const TeH::Ext& a, const TeH::Ext& b) {
+    const TeH::Ext r = TeH::add(a, b);
+    bad |= Fp64::is_zero(r.z);
+    return r;
+  }
+  TeH::Ext dbl(const TeH::Ext& a) {
+    const TeH::Ext r = TeH::dbl(a);
+    bad |= Fp64::is_zero(r.z);
+    return r;
+  }
+};
 // Same Horner as g1h_combine over Edwards partial records.
 inline bool teh_is_identity(const TeH::Ext& p) { return Fp64::is_zero(p.x) && Fp64::is_zero(Fp64::sub(p.y, p.z)); }
-inline TeH::Ext teh_add_skip_identity(const TeH::Ext& acc, const TeH::Ext& p) { return teh_is_identity(p) ? acc : TeH::add(acc, p); }
-inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
+inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0) {
   TeH::Ext acc = TeH::identity();
   for (int b = 16 * num_windows - 1; b >= 0; b--) {
-    acc = TeH::dbl(acc);
+    acc = chk.dbl(acc);
     const int w = b >> 4, l = b & 15;
     if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
     // identity points cost nothing: the records of a rank that folded its windows (g1_fold_tagged) are mostly that
-    if (l < 15) acc = teh_add_skip_identity(acc, teh_from_record_words(base + (size_t)(1 + l) * 48));
-    if (l == 0) acc = teh_add_skip_identity(acc, teh_from_record_words(base));
+    if (l < 15) {
+      const TeH::Ext p = teh_from_record_words(base + (size_t)(1 + l) * 48);
+      if (!teh_is_identity(p)) acc = chk.add(acc, p);
+    }
+    if (l == 0) {
+      const TeH::Ext p = teh_from_record_words(base);
+      if (!teh_is_identity(p)) acc = chk.add(acc, p);
+    }
   }
   return acc;
 }
-inline void teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) { teh_to_wire(teh_horner(partials, num_windows), out); }
+// false: done; true: an exceptional case of the law (out untouched).
+inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+  TeChecked chk;
+  const TeH::Ext r = teh_horner(partials, num_windows, chk);
+  if (chk.bad) return true;
+  teh_to_wire(r, out);
+  return false;
+}
 
 inline void words_from_fp64(const Fp64::El& a, uint32_t* w12) {
   for (int i = 0; i < 6; i++) {
@@ -334,6 +364,8 @@ inline void words_from_fp64(const Fp64::El& a, uint32_t* w12) {
 // by records with the same total -- point 0 of the first one becomes sum_w 2^(16 (w - first)) G_w (one short Horner
 // chain), every other point the identity -- so that the final combine, which skips identity points, is left with
 // its doublings and one addition per rank.  Records of mixed kinds are left as they are.
+// Records whose Horner chain hits an exceptional case of the Edwards law are left as they are too (folding is
+// optional; the final combine then decides).
 inline void g1_fold_tagged(uint32_t* partials, int count) {
   if (count <= 0) return;
   const bool te = window_record_is_te(partials);
@@ -341,7 +373,9 @@ inline void g1_fold_tagged(uint32_t* partials, int count) {
     if (window_record_is_te(partials + (size_t)w * 16 * 48) != te) return;
   uint32_t folded[48];
   if (te) {
-    const TeH::Ext f = teh_horner(partials, count);
+    TeChecked chk;
+    const TeH::Ext f = teh_horner(partials, count, chk);
+    if (chk.bad) return;
     words_from_fp64(f.x, folded);
     words_from_fp64(f.y, folded + 12);
     words_from_fp64(f.t, folded + 24);
@@ -368,15 +402,21 @@ inline void g1_fold_tagged(uint32_t* partials, int count) {
 // Partial records of either kind, window by window (see TE_RECORD_TAG).  All of one kind: one Horner chain.  Mixed
 // (some ranks of a sharded MSM fell back to the Weierstrass path): one chain per kind over its own windows, the
 // Edwards sum is mapped back to the Weierstrass curve and the two sums are added there.
-inline void g1_combine_tagged(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+// Returns true (out untouched) when the Edwards records add up to an exceptional case of their law.
+inline bool g1_combine_tagged(const uint32_t* partials, int num_windows, uint8_t out[96]) {
   uint32_t te_mask = 0;
   for (int w = 0; w < num_windows; w++)
     if (window_record_is_te(partials + (size_t)w * 16 * 48)) te_mask |= 1u << w;
   const uint32_t all = num_windows >= 32 ? 0xffffffffu : ((1u << num_windows) - 1u);
   if (te_mask == all) return teh_combine(partials, num_windows, out);
-  if (te_mask == 0) return g1h_combine(partials, num_windows, out);
+  if (te_mask == 0) {
+    g1h_combine(partials, num_windows, out);
+    return false;
+  }
   uint8_t te_wire[96];
-  const TeH::Ext te_sum = teh_horner(partials, num_windows, all & ~te_mask);
+  TeChecked chk;
+  const TeH::Ext te_sum = teh_horner(partials, num_windows, chk, all & ~te_mask);
+  if (chk.bad) return true;
   G1H::XYZZ acc = g1h_horner(partials, num_windows, te_mask);
   if (!(Fp64::is_zero(te_sum.x) && Fp64::is_zero(Fp64::sub(te_sum.y, te_sum.z)))) {  // not the identity
     teh_to_wire(te_sum, te_wire);
@@ -388,6 +428,7 @@ inline void g1_combine_tagged(const uint32_t* partials, int num_windows, uint8_t
     acc = G1H::madd(acc, q);
   }
   g1h_to_wire(acc, out);
+  return false;
 }
 
 // ---- Edwards tail ----

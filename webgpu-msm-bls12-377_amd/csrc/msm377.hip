@@ -60,7 +60,13 @@ constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
 constexpr uint32_t SEG_MIN = 16;           // entries per accumulation work item (one thread), see auto_seg(); the work-item and overflow buffers are sized for SEG_MIN
 constexpr uint32_t SEG_MAX = 128;
 constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by length 0..seg
-constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2, ERR_TE_EXCEPTIONAL = 4;  // bits of the device error word
+// Bits of the device error word.  The twisted Edwards form reports an exceptional case of its addition law (te377.hpp)
+// with one bit per place it can surface, so that tests can tell which check fired (msm377_ctx_get_fallback_info);
+// any of them makes the call rerun on the Weierstrass path.  MSM377_FB_TAIL is raised by the host tail (fp64_host.hpp
+// TeChecked) and never lives in the device word.
+constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2;
+constexpr int ERR_TE_EXCEPTIONAL = MSM377_FB_ACCUMULATE, ERR_TE_MERGE = MSM377_FB_MERGE, ERR_TE_TREE = MSM377_FB_TREE, ERR_TE_CONVERT = MSM377_FB_CONVERT;
+constexpr int ERR_TE_ANY = ERR_TE_EXCEPTIONAL | ERR_TE_MERGE | ERR_TE_TREE | ERR_TE_CONVERT;
 constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
 
 // ------------------------------------------------------------------ device helpers ----
@@ -82,10 +88,12 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ p, uin
 struct G1Dev {
   static constexpr uint32_t REC_WORDS = 32;  // one base record, 128 bytes
   static constexpr bool HAS_QUAD = true;     // quad-cooperative additions (add_quad below)
-  static constexpr bool IS_XYZZ = true;
   static constexpr uint32_t RAW_WORDS = 24;  // wire: x || y, 48 bytes each
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, ZZ, ZZZ
   static constexpr uint32_t OUT_WORDS = 48;  // a partial-record point: 4 coordinates x 12 u32 (host-tail format)
+  static constexpr uint32_t RECORD_TAG = 0;  // Weierstrass records carry no tag (fp64_host.hpp TE_RECORD_TAG)
+  static constexpr int MADD_PRODUCTS = 10;   // field products per bucket addition (8M + 2S)
+  static constexpr int FORM_ID = MSM377_STAGE_FORM_XYZZ;
   using F = Fp;
   static constexpr uint32_t NL = 13, NW32 = 12;
   static __device__ __forceinline__ Fp::El to64() { return Fp::from_const(G1Consts::TO64); }
@@ -145,10 +153,12 @@ struct G1Dev {
 struct EdDev {
   static constexpr uint32_t REC_WORDS = 32;
   static constexpr bool HAS_QUAD = true;
-  static constexpr bool IS_XYZZ = false;
   static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
   static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
   static constexpr uint32_t OUT_WORDS = 32;  // a partial-record point: 4 coordinates x 8 u32 (host-tail format)
+  static constexpr uint32_t RECORD_TAG = 0;
+  static constexpr int MADD_PRODUCTS = 7;
+  static constexpr int FORM_ID = -1;  // no stage read-back for the Edwards-BLS12 curve
   using F = Fq;
   static constexpr uint32_t NL = 9, NW32 = 8;
   static __device__ __forceinline__ Fq::El to64() { return Fq::from_const(EdConsts::TO64); }
@@ -214,10 +224,12 @@ struct EdDev {
 struct TeDev {
   static constexpr uint32_t REC_WORDS = 64;
   static constexpr bool HAS_QUAD = true;
-  static constexpr bool IS_XYZZ = false;
   static constexpr uint32_t RAW_WORDS = 24;
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, T, Z
   static constexpr uint32_t OUT_WORDS = 48;
+  static constexpr uint32_t RECORD_TAG = TE_RECORD_TAG;  // set in word 11 of every window record's first coordinate
+  static constexpr int MADD_PRODUCTS = 8;
+  static constexpr int FORM_ID = MSM377_STAGE_FORM_TE;
   using F = Fp;
   static constexpr uint32_t NL = 13, NW32 = 12;
   static __device__ __forceinline__ Fp::El to64() { return Fp::from_const(G1Consts::TO64); }
@@ -283,6 +295,7 @@ struct TeDev {
 struct TeAffBase {
   static constexpr uint32_t REC_WORDS = 40;  // (y-x)[13] (y+x)[13] (2dxy)[13] pad[1]
   static constexpr uint32_t RAW_WORDS = 24;
+  static constexpr int MADD_PRODUCTS = 7;
   using Base = Te377::ABase;
   using Pt = Te377::Ext;
   static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
@@ -356,7 +369,7 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restric
   uint32_t w[CV::RAW_WORDS];
   load_words16(raw + i * CV::RAW_WORDS, w, CV::RAW_WORDS / 4);
   uint32_t o[CV::REC_WORDS];
-  if (CV::convert(w, o)) atomicOr(err, ERR_TE_EXCEPTIONAL);
+  if (CV::convert(w, o)) atomicOr(err, ERR_TE_CONVERT);
   uint4* dst = reinterpret_cast<uint4*>(bases + i * CV::REC_WORDS);
 #pragma unroll
   for (int k = 0; k < (int)CV::REC_WORDS / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
@@ -942,7 +955,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
       acc = CV::add(acc, load_point_aos<CV>(src + (size_t)(s - 1) * CV::PT_WORDS));
       bad |= CV::is_bad(acc);
     }
-    if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
+    if (bad) atomicOr(err, ERR_TE_MERGE);
     store_bucket<CV>(buckets, ws, t, acc);
   }
 }
@@ -960,43 +973,8 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
 // Every access is unit-stride across lanes (limb-major bucket layout).  Total work 2 NB
 // additions per window -- the same as the reference's running sum (bpr.template.wgsl:99-107) --
 // at depth 15 instead of 2 * 128 serial additions plus a 15-bit scalar multiplication.
-//
-// k_reduce_first fuses levels 0..2 in registers: thread k < NB/8 loads the 8 buckets
-// k + j NB/8 (j = j2 j1 j0 are index bits 14, 13, 12) and emits
-//     S = sum_j B_j -> B[k],   bit 14: B4+..+B7 -> B[NB/2 + k],
-//     bit 13: B2+B3+B6+B7 -> B[NB/4 + k],   bit 12: B1+B3+B5+B7 -> B[NB/8 + k]
-// with 11 additions (one wave per SIMD: it needs ~6 live points).
-template <class CV>
-__global__ void __launch_bounds__(256, 1) k_reduce_first(uint32_t* __restrict__ buckets) {
-  using Pt = typename CV::Pt;
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // < NB / 8
-  const uint32_t ws = blockIdx.y;
-  constexpr uint32_t Q = NB / 8;
-  Pt b0 = load_bucket<CV>(buckets, ws, k);
-  Pt b1 = load_bucket<CV>(buckets, ws, k + Q);
-  Pt s0123 = CV::add(b0, b1);
-  Pt p12 = b1;
-  Pt b2 = load_bucket<CV>(buckets, ws, k + 2 * Q);
-  Pt b3 = load_bucket<CV>(buckets, ws, k + 3 * Q);
-  Pt s23 = CV::add(b2, b3);
-  p12 = CV::add(p12, b3);
-  s0123 = CV::add(s0123, s23);
-  Pt b4 = load_bucket<CV>(buckets, ws, k + 4 * Q);
-  Pt b5 = load_bucket<CV>(buckets, ws, k + 5 * Q);
-  Pt s4567 = CV::add(b4, b5);
-  p12 = CV::add(p12, b5);
-  Pt b6 = load_bucket<CV>(buckets, ws, k + 6 * Q);
-  Pt b7 = load_bucket<CV>(buckets, ws, k + 7 * Q);
-  Pt s67 = CV::add(b6, b7);
-  p12 = CV::add(p12, b7);
-  store_bucket<CV>(buckets, ws, k + Q, p12);
-  store_bucket<CV>(buckets, ws, k + 2 * Q, CV::add(s23, s67));
-  s4567 = CV::add(s4567, s67);
-  store_bucket<CV>(buckets, ws, k + 4 * Q, s4567);
-  store_bucket<CV>(buckets, ws, k, CV::add(s0123, s4567));
-}
 
-// One level r >= 3 of the reduction (see above): (r + 1) lists of NB/2^(r+1) pair-additions.
+// One level r of the reduction (see above): (r + 1) lists of NB/2^(r+1) pair-additions.
 template <class CV>
 __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
@@ -1014,7 +992,7 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
   // waves skip the addition.
   if (CV::is_stored_identity(b)) return;
   const typename CV::Pt sum = CV::is_stored_identity(a) ? b : CV::add(a, b);
-  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_EXCEPTIONAL);
+  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
   store_bucket<CV>(buckets, ws, x, sum);
 }
 
@@ -1119,7 +1097,7 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
   const uint32_t x = lo + kk, y = x + half;
   const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, ws, x), load_bucket<CV>(buckets, ws, y), q);
-  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_EXCEPTIONAL);
+  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
   // each lane stores one coordinate
   const typename CV::F::El c = coord4(q, sum);
   uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + CV::NL * q) * NB + x;
@@ -1150,7 +1128,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
       acc = add_quad(acc, cur, q);
       bad |= CV::is_bad(acc);
     }
-    if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
+    if (bad) atomicOr(err, ERR_TE_MERGE);
     const typename CV::F::El c = coord4(q, acc);
     uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + CV::NL * q) * NB + t;
 #pragma unroll
@@ -1174,6 +1152,7 @@ __global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restri
   v = CV::F::mul(v, CV::to64());
   uint32_t w[CV::NW32];
   CV::F::template to_words<CV::NW32>(v, w);
+  if (pt == 0 && coord == 0) w[CV::NW32 - 1] |= CV::RECORD_TAG;  // the record names its coordinate system (values are < 2^377: the bit is free)
   uint32_t* o = out + ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
 #pragma unroll
   for (uint32_t j = 0; j < CV::NW32; j++) o[j] = w[j];
@@ -1351,7 +1330,7 @@ struct msm377_ctx {
   uint64_t bases_n = 0;  // resident base count (fixed-base mode)
   uint64_t last_n = 0;
   uint32_t last_wc = 0;
-  bool last_is_g1 = false;
+  int last_form = -1;  // MSM377_STAGE_FORM_* of the buckets the last call left (stage read-backs)
   bool capture = false;
   bool timing = false;
   // First reduction level run with one addition per lane quad.  0 = automatic: the first level whose 4 lanes x additions
@@ -1371,7 +1350,6 @@ struct msm377_ctx {
   bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
   uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
   int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
-  bool reduce_fused = false;  // MSM377_REDUCE_FUSED=1: levels 0..2 fused in registers (measured slower: 0.64 vs 0.51 ms)
   hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
   hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
   hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
@@ -1385,6 +1363,9 @@ struct msm377_ctx {
   int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
   uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
+  int last_products = 0;        // field products per bucket addition of the last accumulation launch (bench.py's int32-mad roof)
+  uint64_t fallback_count = 0;  // reruns on the Weierstrass path after an exceptional case of the Edwards law
+  uint32_t fallback_mask = 0;   // MSM377_FB_* bits of the last one
 };
 
 namespace {
@@ -1393,6 +1374,10 @@ bool hip_ok(msm377_ctx* ctx, hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
   if (ctx) ctx->err = std::string(what) + ": " + hipGetErrorString(e);
   return false;
+}
+void note_fallback(msm377_ctx* ctx, uint32_t mask) {
+  ctx->fallback_count++;
+  ctx->fallback_mask = mask;
 }
 #define HIP_TRY(ctx, call)                            \
   do {                                                \
@@ -1597,6 +1582,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     // The accumulation launches of the two parts run one after the other (the second waits for the first): they
     // are the power-limited kernels, sharing the GPU would only stretch both.
     if (part == 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->acc_done, 0));
+    ctx->last_products = BP::MADD_PRODUCTS;
     {
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL, st, part);
       const dim3 grid((unsigned)((max_items + 255) / 256));
@@ -1635,12 +1621,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   }
   {
     StageTimer t(ctx, MSM377_STAGE_REDUCE, st, part);
-    uint32_t first_level = 0;
-    if (ctx->reduce_fused) {
-      hipLaunchKernelGGL(k_reduce_first<CV>, dim3(NB / 8 / 256, wc), dim3(256), 0, st, buckets);
-      HIP_TRY(ctx, hipGetLastError());
-      first_level = 3;
-    }
+    const uint32_t first_level = 0;
     uint32_t coop_from = ctx->coop_from;
     if (coop_from == 0)
       for (coop_from = 1; coop_from < TREE_LEVELS && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > 65536; coop_from++) {
@@ -1708,7 +1689,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   ctx->last_n = n;
   ctx->last_wc = wc;
   ctx->last_glv = glv;
-  ctx->last_is_g1 = CV::IS_XYZZ;  // the stage read-backs describe the Weierstrass XYZZ buckets
+  ctx->last_form = CV::FORM_ID;
   return MSM377_OK;
 }
 
@@ -1793,12 +1774,17 @@ Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, Db
   return acc;
 }
 
-void te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
+// true: an addition or doubling of the tail hit an exceptional case of the Edwards law (fp64_host.hpp TeChecked;
+// out_xy untouched) -- the caller reruns on the Weierstrass path, exactly as for the GPU-side flag.
+bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
   if (ctx->tail_threads <= 1) return teh_combine(partials, MSM377_NUM_WINDOWS, out_xy);
+  TeChecked chk[4];  // one per block chain (three of them on pool threads), chk[3] also covers the stitching
   const TeH::Ext r = tail_horner_mt<TeH::Ext>(
-      ctx, partials, [](const uint32_t* p, int nw) { return teh_horner(p, nw); }, [](const TeH::Ext& a) { return TeH::dbl(a); },
-      [](const TeH::Ext& a, const TeH::Ext& b) { return TeH::add(a, b); });
+      ctx, partials, [&chk, partials](const uint32_t* p, int nw) { return teh_horner(p, nw, chk[(p - partials) / (4 * 16 * 48)]); },
+      [&chk](const TeH::Ext& a) { return chk[3].dbl(a); }, [&chk](const TeH::Ext& a, const TeH::Ext& b) { return chk[3].add(a, b); });
+  if (chk[0].bad || chk[1].bad || chk[2].bad || chk[3].bad) return true;
   teh_to_wire(r, out_xy);
+  return false;
 }
 
 void xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
@@ -1824,13 +1810,17 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
                               : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
-    if (ctx->h_err[0] & ERR_TE_EXCEPTIONAL) return RC_TE_FALLBACK;
+    if (ctx->h_err[0] & ERR_TE_ANY) {
+      note_fallback(ctx, (uint32_t)(ctx->h_err[0] & ERR_TE_ANY));
+      return RC_TE_FALLBACK;
+    }
     rc = finish_windows(ctx, 0);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    te_tail(ctx, ctx->h_partials, out_xy);
+    const bool bad = te_tail(ctx, ctx->h_partials, out_xy);
     time_tail(ctx, t0);
-    return MSM377_OK;
+    if (bad) note_fallback(ctx, MSM377_FB_TAIL);
+    return bad ? RC_TE_FALLBACK : MSM377_OK;
   }
   if (form == TABLE_XYZZ_GLV) {
     int rc = enqueue_windows<G1Dev>(ctx, d_scalars, n, 0, GLV_WINDOWS, 0, true);
@@ -1957,6 +1947,7 @@ const char* msm377_strerror(int code) {
     case MSM377_ENOMEM: return "out of memory";
     case MSM377_ESTATE: return "call sequence error";
     case MSM377_EGLVRANGE: return "scalar outside the GLV range";
+    case MSM377_EEXCEPTIONAL: return "exceptional case of the twisted Edwards law while combining partial records";
     default: return "unknown error";
   }
 }
@@ -1970,7 +1961,6 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (!ctx) return MSM377_ENOMEM;
   ctx->device = device;
   ctx->cap = max_points;
-  if (const char* e = getenv("MSM377_REDUCE_FUSED")) ctx->reduce_fused = atoi(e) != 0;
   if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
@@ -2108,16 +2098,20 @@ int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
     rc = te ? run_chunked_upload<TeDev>(ctx, points, scalars, n) : run_chunked_upload<G1Dev>(ctx, points, scalars, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
-    if (!(te && (ctx->h_err[0] & ERR_TE_EXCEPTIONAL))) {
+    if (!(te && (ctx->h_err[0] & ERR_TE_ANY))) {
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
+      bool bad = false;
       if (te)
-        te_tail(ctx, ctx->h_partials, out_xy);
+        bad = te_tail(ctx, ctx->h_partials, out_xy);
       else
         xyzz_tail(ctx, ctx->h_partials, out_xy);
       time_tail(ctx, t0);
-      return MSM377_OK;
+      if (!bad) return MSM377_OK;
+      note_fallback(ctx, MSM377_FB_TAIL);
+    } else {
+      note_fallback(ctx, (uint32_t)(ctx->h_err[0] & ERR_TE_ANY));
     }
     // exceptional case of the Edwards law: everything is on the device by now, rerun in one piece below
   } else {
@@ -2284,7 +2278,10 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
     if (b > 0) {
       const int slot = (int)((b - 1) & 1);
       HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
-      if (te && (ctx->h_err[slot] & ERR_TE_EXCEPTIONAL)) te_fallback = true;
+      if (te && !te_fallback && (ctx->h_err[slot] & ERR_TE_ANY)) {
+        te_fallback = true;
+        note_fallback(ctx, (uint32_t)(ctx->h_err[slot] & ERR_TE_ANY));
+      }
       if (te_fallback) continue;
       if (glv && (ctx->h_err[slot] & ERR_GLV_RANGE)) {
         redo.push_back(b - 1);
@@ -2295,9 +2292,12 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
       }
-      if (te)
-        teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
-      else
+      if (te) {
+        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1))) {
+          te_fallback = true;
+          note_fallback(ctx, MSM377_FB_TAIL);
+        }
+      } else
         g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
     }
   }
@@ -2322,43 +2322,69 @@ int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n
   return msm377_g1_msm_fixed_base_device(ctx, ctx->d_raw_scalars, n, out_xy);
 }
 
-int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin,
-                                     uint32_t win_count, uint8_t* partials_out) {
-  if (!partials_out) return MSM377_EINVAL;
+// Windows [win_begin, win_begin + win_count) of a G1 MSM; the records go to a host buffer, a device buffer, or both.
+static int window_partials(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin, uint32_t win_count,
+                           uint8_t* host_out, void* dev_out) {
   int rc = check_args(ctx, d_points, d_scalars, n, true);
   if (rc) return rc;
   if (win_count == 0 || win_begin >= MSM377_NUM_WINDOWS || win_count > MSM377_NUM_WINDOWS - win_begin) {
     ctx->err = "window range outside 0..16";
     return MSM377_EINVAL;
   }
+  if ((uintptr_t)dev_out & 15) {
+    ctx->err = "device output pointer must be 16-byte aligned";
+    return MSM377_EINVAL;
+  }
+  const size_t bytes = (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n == 0) {  // identity partials: ZZ = 0 everywhere
-    memset(partials_out, 0, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
+    if (host_out) memset(host_out, 0, bytes);
+    if (dev_out) HIP_TRY(ctx, hipMemset(dev_out, 0, bytes));
     return MSM377_OK;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->bases_n = 0;
-  if (ctx->g1_form == 1) {  // twisted Edwards form; records tagged (fp64_host.hpp TE_RECORD_TAG)
+  // The records are complete in ctx->d_partials (slot 0) once the call's completion event has fired; the copy
+  // to the caller's device buffer rides the same stream and the call returns with that stream idle, so a
+  // collective on any other stream may read the buffer.
+  auto deliver = [&]() -> int {
+    if (host_out) memcpy(host_out, ctx->h_partials, bytes);
+    if (dev_out) {
+      HIP_TRY(ctx, hipMemcpyAsync(dev_out, ctx->d_partials, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MSM377_OK;
+  };
+  if (ctx->g1_form == 1) {  // twisted Edwards form; k_gather_partials tags the records (fp64_host.hpp TE_RECORD_TAG)
     rc = convert_bases<TeDev>(ctx, (const uint32_t*)d_points, n);
     if (rc) return rc;
     rc = enqueue_windows<TeDev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count, 0);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
-    if ((ctx->h_err[0] & ERR_TE_EXCEPTIONAL) == 0) {
+    if ((ctx->h_err[0] & ERR_TE_ANY) == 0) {
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
-      memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
-      for (uint32_t w = 0; w < win_count; w++)
-        reinterpret_cast<uint32_t*>(partials_out)[(size_t)w * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS + 11] |= TE_RECORD_TAG;
-      return MSM377_OK;
+      return deliver();
     }
+    note_fallback(ctx, (uint32_t)(ctx->h_err[0] & ERR_TE_ANY));
     // an exceptional case of the Edwards law in THESE windows: they alone rerun below, untagged
   }
   rc = convert_bases<G1Dev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
   rc = run_windows<G1Dev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count);
   if (rc) return rc;
-  memcpy(partials_out, ctx->h_partials, (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES);
-  return MSM377_OK;
+  return deliver();
+}
+
+int msm377_g1_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin,
+                                     uint32_t win_count, uint8_t* partials_out) {
+  if (!partials_out) return MSM377_EINVAL;
+  return window_partials(ctx, d_points, d_scalars, n, win_begin, win_count, partials_out, nullptr);
+}
+
+int msm377_g1_window_partials_resident(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin,
+                                       uint32_t win_count, void* d_partials_out) {
+  if (!d_partials_out) return MSM377_EINVAL;
+  return window_partials(ctx, d_points, d_scalars, n, win_begin, win_count, nullptr, d_partials_out);
 }
 
 int msm377_g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin,
@@ -2393,8 +2419,27 @@ int msm377_g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, 
 
 int msm377_g1_combine_window_partials(const uint8_t* partials, uint32_t num_windows, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3) || num_windows == 0 || num_windows > MSM377_NUM_WINDOWS) return MSM377_EINVAL;
-  g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), (int)num_windows, out_xy);
-  return MSM377_OK;
+  return g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), (int)num_windows, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
+}
+
+int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uint8_t out_xy[96]) {
+  if (!ctx || !partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
+  const uint32_t* rec = reinterpret_cast<const uint32_t*>(partials);
+  bool all_te = true, all_w = true;
+  for (int w = 0; w < MSM377_NUM_WINDOWS; w++) {
+    const bool te = window_record_is_te(rec + (size_t)w * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS);
+    all_te = all_te && te;
+    all_w = all_w && !te;
+  }
+  int rc = MSM377_OK;
+  if (all_te)
+    rc = te_tail(ctx, rec, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
+  else if (all_w)
+    xyzz_tail(ctx, rec, out_xy);
+  else
+    rc = g1_combine_tagged(rec, MSM377_NUM_WINDOWS, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
+  if (rc) ctx->err = "the partial records add up to an exceptional case of the twisted Edwards law (points outside the prime-order subgroup): recompute them in form 0";
+  return rc;
 }
 
 int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count) {
@@ -2405,8 +2450,7 @@ int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count) {
 
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
-  g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy);
-  return MSM377_OK;
+  return g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
 }
 
 int msm377_g1_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out) {
@@ -2431,7 +2475,7 @@ int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled) {
 
 int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint32_t* row_ptr, uint32_t* val_idx, uint32_t* buckets) {
   if (!ctx) return MSM377_EINVAL;
-  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc || !ctx->last_is_g1 || ctx->last_glv) {
+  if (!ctx->capture || ctx->last_n == 0 || slot >= ctx->last_wc || ctx->last_form < 0 || ctx->last_glv) {
     ctx->err = "no captured stage data for that window slot";
     return MSM377_ESTATE;
   }
@@ -2453,6 +2497,8 @@ int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint3
   return MSM377_OK;
 }
 
+int msm377_ctx_get_stage_form(const msm377_ctx* ctx) { return (ctx && ctx->capture && ctx->last_n) ? ctx->last_form : -1; }
+
 int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]) {
   if (!xyzz || !out_xy) return MSM377_EINVAL;
   g1h_to_wire(g1h_from_device_words(xyzz), out_xy);
@@ -2468,6 +2514,15 @@ int msm377_ctx_set_glv(msm377_ctx* ctx, int mode) {
 int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form) {
   if (!ctx || form < 0 || form > 1) return MSM377_EINVAL;
   ctx->g1_form = form;
+  return MSM377_OK;
+}
+
+int msm377_ctx_get_products_per_addition(const msm377_ctx* ctx) { return ctx ? ctx->last_products : 0; }
+
+int msm377_ctx_get_fallback_info(const msm377_ctx* ctx, uint64_t* count, uint32_t* last_mask) {
+  if (!ctx) return MSM377_EINVAL;
+  if (count) *count = ctx->fallback_count;
+  if (last_mask) *last_mask = ctx->fallback_mask;
   return MSM377_OK;
 }
 

@@ -20,7 +20,9 @@ WINDOW_PARTIAL_BYTES = PARTIAL_POINTS * RECORD_POINT_WORDS * 4
 NUM_BUCKETS = 32768
 STAGE_NAMES = ("convert", "decompose", "sort", "accumulate", "reduce", "tail", "accumulate_kernel")
 
-OK, EINVAL, EHIP, ESCALAR, ENOMEM, ESTATE, EGLVRANGE = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, EHIP, ESCALAR, ENOMEM, ESTATE, EGLVRANGE, EEXCEPTIONAL = 0, -1, -2, -3, -4, -5, -6, -7
+# msm377_ctx_get_fallback_info: where an exceptional case of the twisted Edwards law surfaced (include/msm377.h)
+FB_ACCUMULATE, FB_MERGE, FB_TREE, FB_TAIL, FB_CONVERT = 4, 8, 16, 32, 64
 GLV_WINDOWS = 8
 
 _LIB = None
@@ -79,7 +81,10 @@ def load_library():
         "msm377_g1_msm_fixed_base_device": (i32, [vp, vp, u64, vp]),
         "msm377_g1_msm_fixed_base_batch_device": (i32, [vp, vp, u64, u32, vp]),
         "msm377_g1_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
+        "msm377_g1_window_partials_resident": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_combine_partials": (i32, [vp, vp]),
+        "msm377_g1_combine_partials_ctx": (i32, [vp, vp, vp]),
+        "msm377_ctx_get_fallback_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u32)]),
         "msm377_g1_glv_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_combine_window_partials": (i32, [vp, u32, vp]),
         "msm377_g1_generate_bases_device": (i32, [vp, u64, u64, vp]),
@@ -94,6 +99,8 @@ def load_library():
         "msm377_ctx_set_g1_form": (i32, [vp, i32]),
         "msm377_ctx_set_timing": (i32, [vp, i32]),
         "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
+        "msm377_ctx_get_products_per_addition": (i32, [vp]),
+        "msm377_ctx_get_stage_form": (i32, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -241,6 +248,36 @@ class MsmEngine:
         )
         return out.raw[: win_count * WINDOW_PARTIAL_BYTES]
 
+    def window_partials_resident(self, d_points: int, d_scalars: int, n: int, win_begin: int, win_count: int, d_partials_out: int):
+        """The same records left in DEVICE memory at d_partials_out (win_count x WINDOW_PARTIAL_BYTES): the multi-GPU
+        exchange reads them there (msm377_g1_window_partials_resident)."""
+        self._check(
+            self._lib.msm377_g1_window_partials_resident(self._ctx, d_points, d_scalars, int(n), int(win_begin), int(win_count), d_partials_out),
+            "msm377_g1_window_partials_resident",
+        )
+
+    def combine_partials(self, partials) -> bytes:
+        """Host tail over all 16 windows' records on the context's tail threads (msm377_g1_combine_partials_ctx);
+        ``partials`` is bytes or anything with a buffer address of 16 x WINDOW_PARTIAL_BYTES bytes.  Raises
+        MsmError(EEXCEPTIONAL) when Edwards records add up to an exceptional case (recompute in form 0)."""
+        if isinstance(partials, (bytes, bytearray)):
+            if len(partials) != NUM_WINDOWS * WINDOW_PARTIAL_BYTES:
+                raise ValueError("expected %d bytes of partials" % (NUM_WINDOWS * WINDOW_PARTIAL_BYTES))
+            src = (ctypes.c_uint32 * (len(partials) // 4)).from_buffer_copy(partials)
+            addr = ctypes.addressof(src)
+        else:
+            addr = int(partials)
+        out = ctypes.create_string_buffer(96)
+        self._check(self._lib.msm377_g1_combine_partials_ctx(self._ctx, addr, ctypes.addressof(out)), "msm377_g1_combine_partials_ctx")
+        return out.raw
+
+    def fallback_info(self) -> Tuple[int, int]:
+        """(count, last_mask): reruns on the Weierstrass path after an exceptional case of the Edwards law, and the
+        FB_* bits of the last one."""
+        count, mask = ctypes.c_uint64(), ctypes.c_uint32()
+        self._check(self._lib.msm377_ctx_get_fallback_info(self._ctx, ctypes.byref(count), ctypes.byref(mask)), "msm377_ctx_get_fallback_info")
+        return int(count.value), int(mask.value)
+
     def glv_window_partials_device(self, d_points: int, d_scalars: int, n: int, win_begin: int, win_count: int) -> bytes:
         """Same behind the GLV front end (8 windows); raises MsmError(EGLVRANGE) for out-of-range scalars."""
         out = ctypes.create_string_buffer(max(1, win_count) * WINDOW_PARTIAL_BYTES)
@@ -292,6 +329,10 @@ class MsmEngine:
                 res[k] = v
         return res
 
+    def stage_form(self) -> int:
+        """Coordinate system of the captured buckets: 0 = Weierstrass XYZZ, 1 = twisted Edwards (X, Y, T, Z), -1 = none."""
+        return int(self._lib.msm377_ctx_get_stage_form(self._ctx))
+
     def set_g1_form(self, form="edwards"):
         """Internal coordinates of the G1 full-MSM entry points: "edwards" / 1 (default, csrc/te377.hpp) or
         "weierstrass" / 0 (XYZZ behind the GLV front end)."""
@@ -312,6 +353,11 @@ class MsmEngine:
         arr = (ctypes.c_double * len(STAGE_NAMES))()
         self._check(self._lib.msm377_ctx_get_stage_ms(self._ctx, ctypes.addressof(arr)), "msm377_ctx_get_stage_ms")
         return dict(zip(STAGE_NAMES, list(arr)))
+
+
+    def accumulate_products(self) -> int:
+        """Field products per bucket addition of the last accumulation launch (10 / 8 / 7)."""
+        return int(self._lib.msm377_ctx_get_products_per_addition(self._ctx))
 
 
 def _check_lengths(points: bytes, scalars: bytes) -> int:

@@ -10,7 +10,7 @@ rank (msm377_g1_combine_partials).
 """
 from typing import Callable, Optional, Tuple
 
-from .engine import GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, combine_partials_bytes, fold_partials_bytes
+from .engine import EEXCEPTIONAL, GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, MsmError, combine_partials_bytes, fold_partials_bytes
 
 
 def windows_for_rank(rank: int, world_size: int, num_windows: int = NUM_WINDOWS) -> Tuple[int, int]:
@@ -69,6 +69,38 @@ class ShardedMsm:
         flat = self.recv_host.numpy()
         parts = [flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts)]
         return combine_partials_bytes(b"".join(parts), self.num_windows)
+
+    def run_resident(self, write_records: Callable[[int, int, int], None], combine: Optional[Callable[[bytes], bytes]] = None,
+                     rerun_weierstrass: Optional[Callable[[int, int, int], None]] = None) -> bytes:
+        """The RCCL path: the records never visit the host before the exchange.
+
+        ``write_records(win_begin, win_count, d_out)`` leaves this rank's window records in device memory at
+        ``d_out`` (MsmEngine.window_partials_resident bound to the resident inputs; it returns with the engine's
+        stream idle).  ONE all-gather straight from that buffer over RCCL/xGMI follows, then one D2H of the
+        gathered records (49 KB at most) and the host combine on every rank -- ``combine`` is normally
+        MsmEngine.combine_partials (the context's tail threads).  Records that add up to an exceptional case of
+        the twisted Edwards law (MsmError EEXCEPTIONAL; every rank sees the same records, so every rank gets the
+        same verdict) are recomputed through ``rerun_weierstrass`` (same signature; the engine in form 0) and
+        exchanged again.
+        """
+        if self.world == 1:
+            raise ValueError("run_resident is the multi-rank path; a single rank calls the engine's full MSM")
+        import torch.distributed as dist
+
+        for attempt in (0, 1):
+            fn = write_records if attempt == 0 else rerun_weierstrass
+            if self.count:
+                fn(self.begin, self.count, self.send_dev.data_ptr())
+            dist.all_gather_into_tensor(self.recv_dev, self.send_dev, group=self.group)
+            self.recv_host.copy_(self.recv_dev)  # synchronising D2H
+            flat = self.recv_host.numpy()
+            parts = b"".join(flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts))
+            try:
+                return combine(parts) if combine is not None else combine_partials_bytes(parts, self.num_windows)
+            except MsmError as e:
+                if e.code != EEXCEPTIONAL or attempt == 1 or rerun_weierstrass is None:
+                    raise
+        raise AssertionError("unreachable")
 
 
 def sharded_msm(

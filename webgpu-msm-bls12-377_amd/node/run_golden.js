@@ -20,8 +20,21 @@ const { compute_msm, version } = require('./compute_msm.js');
   }
   const r2 = await compute_msm(pts, ks, false);
   if (r2.x !== r.x || r2.y !== r.y) throw new Error('BigIntPoint[] form disagrees with Buffer form');
+  // third form: U32ArrayPoint[] / Uint32Array[] -- most-significant word first (src/reference/webgpu/utils.ts:41-61)
+  const u32 = (v, bits) => {
+    const words = new Uint32Array(bits / 32);
+    for (let i = words.length - 1; i >= 0; i--) {
+      words[i] = Number(v & BigInt(0xffffffff));
+      v >>= BigInt(32);
+    }
+    return words;
+  };
+  const pts32 = pts.map((p) => ({ x: u32(p.x, 384), y: u32(p.y, 384) }));
+  const ks32 = ks.map((k) => u32(k, 256));
+  const r3 = await compute_msm(pts32, ks32, false);
+  if (r3.x !== r.x || r3.y !== r.y) throw new Error('U32ArrayPoint[] form disagrees with Buffer form');
   const empty = await compute_msm(Buffer.alloc(0), Buffer.alloc(0), false);
-  console.log(JSON.stringify({ x: r.x.toString(), y: r.y.toString(), empty_x: empty.x.toString(), empty_y: empty.y.toString(), version: version() }));
+  console.log(JSON.stringify({ forms: 3, x: r.x.toString(), y: r.y.toString(), empty_x: empty.x.toString(), empty_y: empty.y.toString(), version: version() }));
 })().catch((e) => {
   console.error(String(e));
   process.exit(1);
