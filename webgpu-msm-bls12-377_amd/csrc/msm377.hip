@@ -24,8 +24,8 @@
 //   row_ptr  W x 32770 u32: CSR offsets over keys |d| in 0..32768 (the reference keeps 65537
 //            signed rows; here +t and -t share row t and the sign rides in val_idx bit 31)
 //   val_idx  W x n u32: point index | sign << 31
-//   buckets  W x 52 x NB u32, limb-major ("SoA"): word j of bucket t at [(w*52+j)*NB + t-1],
-//            so thread-per-bucket loads/stores are fully coalesced
+//   buckets  W x NB records of 256 bytes, point-major: four 64-byte coordinate slots (13 limbs + 3 zero words);
+//            bucket t (key t + 1) of window slot w at record w * NB + t -- one lane writes whole lines
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -55,6 +55,7 @@ constexpr uint32_t NB = 32768;     // buckets per window: |d| = 1..32768
 constexpr uint32_t NBIN = NB + 1;  // sort keys 0..32768 (key 0 = digit 0, never accumulated)
 constexpr uint32_t RP = NBIN + 1;  // row_ptr entries per window
 constexpr uint32_t PT_WORDS = 52;  // X, Y, ZZ, ZZZ
+constexpr uint32_t BKT_WORDS = 64; // the largest bucket record (four 64-byte coordinate slots), sizes the shared buffers
 constexpr uint32_t MAX_SORT_BLOCKS = 256;  // (window slot, chunk) blocks of the partition pass
 constexpr uint32_t TREE_LEVELS = 15;       // log2(NB)
 constexpr uint32_t SEG_MIN = 16;           // entries per accumulation work item (one thread), see auto_seg(); the work-item and overflow buffers are sized for SEG_MIN
@@ -90,6 +91,8 @@ struct G1Dev {
   static constexpr bool HAS_QUAD = true;     // quad-cooperative additions (add_quad below)
   static constexpr uint32_t RAW_WORDS = 24;  // wire: x || y, 48 bytes each
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, ZZ, ZZZ
+  static constexpr uint32_t COORD_WORDS = 16;  // a coordinate's slot in a bucket record (13 limbs + 3 pad: 64 bytes)
+  static constexpr uint32_t BKT_WORDS = 4 * COORD_WORDS;
   static constexpr uint32_t OUT_WORDS = 48;  // a partial-record point: 4 coordinates x 12 u32 (host-tail format)
   static constexpr uint32_t RECORD_TAG = 0;  // Weierstrass records carry no tag (fp64_host.hpp TE_RECORD_TAG)
   static constexpr int MADD_PRODUCTS = 10;   // field products per bucket addition (8M + 2S)
@@ -155,6 +158,8 @@ struct EdDev {
   static constexpr bool HAS_QUAD = true;
   static constexpr uint32_t RAW_WORDS = 16;  // wire: x || y, 32 bytes each
   static constexpr uint32_t PT_WORDS = 36;   // X, Y, T, Z
+  static constexpr uint32_t COORD_WORDS = 12;  // 9 limbs + 3 pad: 48 bytes
+  static constexpr uint32_t BKT_WORDS = 4 * COORD_WORDS;
   static constexpr uint32_t OUT_WORDS = 32;  // a partial-record point: 4 coordinates x 8 u32 (host-tail format)
   static constexpr uint32_t RECORD_TAG = 0;
   static constexpr int MADD_PRODUCTS = 7;
@@ -226,6 +231,8 @@ struct TeDev {
   static constexpr bool HAS_QUAD = true;
   static constexpr uint32_t RAW_WORDS = 24;
   static constexpr uint32_t PT_WORDS = 52;   // X, Y, T, Z
+  static constexpr uint32_t COORD_WORDS = 16;
+  static constexpr uint32_t BKT_WORDS = 4 * COORD_WORDS;
   static constexpr uint32_t OUT_WORDS = 48;
   static constexpr uint32_t RECORD_TAG = TE_RECORD_TAG;  // set in word 11 of every window record's first coordinate
   static constexpr int MADD_PRODUCTS = 8;
@@ -326,37 +333,60 @@ struct TeAffBase {
   static __device__ __forceinline__ Pt first(const Base& q, bool negq) { return Te377::from_base_affine(q, negq); }
 };
 
-// Limb-major bucket array: word j of bucket t of window slot ws at [(ws * PT_WORDS + j) * NB + t].
+// Bucket records are point-major: coordinate c of a point sits in its own 16-byte-aligned slot of COORD_WORDS words
+// (13 limbs + 3 zero words = 64 bytes for the 377-bit field: a G1 bucket is exactly two 128-byte lines), bucket t of
+// window slot ws at record ws * NB + t.  Round 1 kept the buckets limb-major so that the thread-per-bucket reduction
+// levels were unit-stride -- but the accumulation kernel, which writes every bucket once, hands its work items out
+// sorted by LENGTH, so adjacent lanes hold unrelated buckets and each of its 52 four-byte stores per bucket left L2
+// as a 32-byte partial write: 0.69 GB written per launch for 0.075 GB of buckets (rocprofv3 WRITE_SIZE,
+// profiles/r01_te).  Here a lane writes its bucket as 16 full 16-byte stores into its own two lines.  The overflow
+// partials of split rows use the same record.
 template <class CV>
-__device__ __forceinline__ typename CV::Pt load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
-  const uint32_t* p = b + (size_t)ws * CV::PT_WORDS * NB + t;
+__device__ __forceinline__ typename CV::Pt load_record(const uint32_t* __restrict__ p) {
   uint32_t w[CV::PT_WORDS];
 #pragma unroll
-  for (uint32_t j = 0; j < CV::PT_WORDS; j++) w[j] = p[(size_t)j * NB];
+  for (uint32_t c = 0; c < 4; c++) {
+    const uint4* s = reinterpret_cast<const uint4*>(p + c * CV::COORD_WORDS);
+#pragma unroll
+    for (uint32_t k = 0; k < CV::NL / 4; k++) {
+      const uint4 v = s[k];
+      w[c * CV::NL + 4 * k + 0] = v.x;
+      w[c * CV::NL + 4 * k + 1] = v.y;
+      w[c * CV::NL + 4 * k + 2] = v.z;
+      w[c * CV::NL + 4 * k + 3] = v.w;
+    }
+    static_assert(CV::NL % 4 == 1, "one limb beyond the 16-byte groups");
+    w[c * CV::NL + CV::NL - 1] = p[c * CV::COORD_WORDS + CV::NL - 1];
+  }
   return CV::from_words(w);
+}
+// One coordinate (NL limbs, the slot's pad words written as zero so that whole 16-byte groups -- whole lines -- go out).
+template <class CV>
+__device__ __forceinline__ void store_coord(uint32_t* __restrict__ slot, const uint32_t* l) {
+  uint4* d = reinterpret_cast<uint4*>(slot);
+#pragma unroll
+  for (uint32_t k = 0; k < CV::NL / 4; k++) d[k] = make_uint4(l[4 * k], l[4 * k + 1], l[4 * k + 2], l[4 * k + 3]);
+  d[CV::NL / 4] = make_uint4(l[CV::NL - 1], 0u, 0u, 0u);
+  static_assert(CV::COORD_WORDS == (CV::NL / 4 + 1) * 4, "slot = limbs rounded up to 16 bytes");
+}
+template <class CV>
+__device__ __forceinline__ void store_record(uint32_t* __restrict__ p, const typename CV::Pt& r) {
+  uint32_t w[CV::PT_WORDS];
+  CV::to_words(r, w);
+#pragma unroll
+  for (uint32_t c = 0; c < 4; c++) store_coord<CV>(p + c * CV::COORD_WORDS, w + c * CV::NL);
+}
+template <class CV>
+__device__ __forceinline__ uint32_t* bucket_ptr(uint32_t* b, uint32_t ws, uint32_t t) { return b + ((size_t)ws * NB + t) * CV::BKT_WORDS; }
+template <class CV>
+__device__ __forceinline__ const uint32_t* bucket_ptr(const uint32_t* b, uint32_t ws, uint32_t t) { return b + ((size_t)ws * NB + t) * CV::BKT_WORDS; }
+template <class CV>
+__device__ __forceinline__ typename CV::Pt load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
+  return load_record<CV>(bucket_ptr<CV>(b, ws, t));
 }
 template <class CV>
 __device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t ws, uint32_t t, const typename CV::Pt& r) {
-  uint32_t* p = b + (size_t)ws * CV::PT_WORDS * NB + t;
-  uint32_t w[CV::PT_WORDS];
-  CV::to_words(r, w);
-#pragma unroll
-  for (uint32_t j = 0; j < CV::PT_WORDS; j++) p[(size_t)j * NB] = w[j];
-}
-// Point-major ("AoS") copy for the overflow partials: PT_WORDS is a multiple of 4.
-template <class CV>
-__device__ __forceinline__ void store_point_aos(uint32_t* __restrict__ dst, const typename CV::Pt& r) {
-  uint32_t w[CV::PT_WORDS];
-  CV::to_words(r, w);
-  uint4* d = reinterpret_cast<uint4*>(dst);
-#pragma unroll
-  for (uint32_t q = 0; q < CV::PT_WORDS / 4; q++) d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-}
-template <class CV>
-__device__ __forceinline__ typename CV::Pt load_point_aos(const uint32_t* __restrict__ src) {
-  uint32_t w[CV::PT_WORDS];
-  load_words16(src, w, CV::PT_WORDS / 4);
-  return CV::from_words(w);
+  store_record<CV>(bucket_ptr<CV>(b, ws, t), r);
 }
 
 // ------------------------------------------------------------------------ kernels ----
@@ -931,7 +961,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   if (it.seg == 0) {
     store_bucket<CV>(buckets, ws, t, acc);
   } else {
-    store_point_aos<CV>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * CV::PT_WORDS, acc);
+    store_record<CV>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * CV::BKT_WORDS, acc);
   }
 }
 
@@ -949,10 +979,10 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
     const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row / NB, t = row % NB;
     typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
-    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::PT_WORDS;
+    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::BKT_WORDS;
     bool bad = false;
     for (uint32_t s = 1; s < nseg; s++) {
-      acc = CV::add(acc, load_point_aos<CV>(src + (size_t)(s - 1) * CV::PT_WORDS));
+      acc = CV::add(acc, load_record<CV>(src + (size_t)(s - 1) * CV::BKT_WORDS));
       bad |= CV::is_bad(acc);
     }
     if (bad) atomicOr(err, ERR_TE_MERGE);
@@ -970,7 +1000,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
 // which leaves the untouched upper half [NB/2^(r+1), NB/2^r) = "index bit 14-r set" as a
 // contiguous list that later levels halve the same way,
 //     B[lo + k] += B[lo + k + NB/2^(r+1)],  lo = NB/2^(r'+1) for every earlier level r' < r.
-// Every access is unit-stride across lanes (limb-major bucket layout).  Total work 2 NB
+// Adjacent lanes touch adjacent 256-byte bucket records.  Total work 2 NB
 // additions per window -- the same as the reference's running sum (bpr.template.wgsl:99-107) --
 // at depth 15 instead of 2 * 128 serial additions plus a 15-bit scalar multiplication.
 
@@ -1100,9 +1130,7 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
   // each lane stores one coordinate
   const typename CV::F::El c = coord4(q, sum);
-  uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + CV::NL * q) * NB + x;
-#pragma unroll
-  for (int j = 0; j < (int)CV::NL; j++) base[(size_t)j * NB] = c.l[j];
+  store_coord<CV>(bucket_ptr<CV>(buckets, ws, x) + q * CV::COORD_WORDS, c.l);
 }
 
 // Quad per split row: bucket += its overflow partials.
@@ -1119,20 +1147,18 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
     const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row / NB, t = row % NB;
     typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
-    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::PT_WORDS;
-    typename CV::Pt nxt = load_point_aos<CV>(src);
+    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::BKT_WORDS;
+    typename CV::Pt nxt = load_record<CV>(src);
     bool bad = false;
     for (uint32_t s = 1; s < nseg; s++) {
       const typename CV::Pt cur = nxt;
-      if (s + 1 < nseg) nxt = load_point_aos<CV>(src + (size_t)s * CV::PT_WORDS);
+      if (s + 1 < nseg) nxt = load_record<CV>(src + (size_t)s * CV::BKT_WORDS);
       acc = add_quad(acc, cur, q);
       bad |= CV::is_bad(acc);
     }
     if (bad) atomicOr(err, ERR_TE_MERGE);
     const typename CV::F::El c = coord4(q, acc);
-    uint32_t* base = buckets + ((size_t)ws * CV::PT_WORDS + CV::NL * q) * NB + t;
-#pragma unroll
-    for (int j = 0; j < (int)CV::NL; j++) base[(size_t)j * NB] = c.l[j];
+    store_coord<CV>(bucket_ptr<CV>(buckets, ws, t) + q * CV::COORD_WORDS, c.l);
   }
 }
 
@@ -1148,7 +1174,7 @@ __global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restri
   const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
   typename CV::F::El v;
 #pragma unroll
-  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = buckets[((size_t)ws * CV::PT_WORDS + coord * CV::NL + j) * NB + x];
+  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, ws, x)[coord * CV::COORD_WORDS + j];
   v = CV::F::mul(v, CV::to64());
   uint32_t w[CV::NW32];
   CV::F::template to_words<CV::NW32>(v, w);
@@ -1520,11 +1546,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   SortElem* sort_temp = ctx->d_sort_temp + (size_t)pv.ws0 * n;
   uint32_t* row_ptr = ctx->d_row_ptr + (size_t)pv.ws0 * RP;
   uint32_t* val_idx = ctx->d_val_idx + (size_t)pv.ws0 * n;
-  uint32_t* buckets = ctx->d_buckets + (size_t)pv.ws0 * CV::PT_WORDS * NB;
+  uint32_t* buckets = ctx->d_buckets + (size_t)pv.ws0 * CV::BKT_WORDS * NB;
   uint32_t* row_ovf_base = ctx->d_row_ovf_base + (size_t)pv.ws0 * NB;
   uint32_t* split_rows = ctx->d_split_rows + (size_t)pv.ws0 * NB;
   WorkItem* work = ctx->d_work + pv.work_off;
-  uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::PT_WORDS;
+  uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::BKT_WORDS;
   const uint32_t* bases = ctx->d_bases + ph.base_first * BP::REC_WORDS;
   uint32_t* meta_block = ctx->d_work_meta + (size_t)part * META_BLOCK_WORDS;  // [work-list counters | key_max[16]]
   uint32_t* key_max = meta_block + (2 * SEG_BINS + 4);
@@ -1617,7 +1643,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   }  // ph.front
   if (!ph.back) return MSM377_OK;
   if (ctx->capture) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, buckets, (size_t)wc * CV::PT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_buckets_snap, buckets, (size_t)wc * CV::BKT_WORDS * NB * 4, hipMemcpyDeviceToDevice, st));
   }
   {
     StageTimer t(ctx, MSM377_STAGE_REDUCE, st, part);
@@ -2001,13 +2027,13 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_sort_temp, cap * MSM377_NUM_WINDOWS * sizeof(SortElem));
   dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
   dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
-  dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4);
+  dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * BKT_WORDS * NB * 4);
   dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
   dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * sizeof(WorkItem));
   dalloc((void**)&ctx->d_work_meta, (size_t)2 * META_BLOCK_WORDS * 4);  // one block per pipeline part
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
-  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * PT_WORDS * 4);
+  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * BKT_WORDS * 4);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
@@ -2467,7 +2493,7 @@ int msm377_ctx_set_stage_capture(msm377_ctx* ctx, int enabled) {
   if (!ctx) return MSM377_EINVAL;
   if (enabled && !ctx->d_buckets_snap) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (hipMalloc((void**)&ctx->d_buckets_snap, (size_t)MSM377_NUM_WINDOWS * PT_WORDS * NB * 4) != hipSuccess) return MSM377_ENOMEM;
+    if (hipMalloc((void**)&ctx->d_buckets_snap, (size_t)MSM377_NUM_WINDOWS * BKT_WORDS * NB * 4) != hipSuccess) return MSM377_ENOMEM;
   }
   ctx->capture = enabled != 0;
   return MSM377_OK;
@@ -2485,12 +2511,13 @@ int msm377_g1_read_stage(msm377_ctx* ctx, uint32_t slot, uint16_t* digits, uint3
   if (row_ptr) HIP_TRY(ctx, hipMemcpy(row_ptr, ctx->d_row_ptr + (size_t)slot * RP, RP * 4, hipMemcpyDeviceToHost));
   if (val_idx) HIP_TRY(ctx, hipMemcpy(val_idx, ctx->d_val_idx + (size_t)slot * n, n * 4, hipMemcpyDeviceToHost));
   if (buckets) {
-    uint32_t* tmp = (uint32_t*)malloc((size_t)PT_WORDS * NB * 4);
+    uint32_t* tmp = (uint32_t*)malloc((size_t)BKT_WORDS * NB * 4);
     if (!tmp) return MSM377_ENOMEM;
-    hipError_t e = hipMemcpy(tmp, ctx->d_buckets_snap + (size_t)slot * PT_WORDS * NB, (size_t)PT_WORDS * NB * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess)
+    hipError_t e = hipMemcpy(tmp, ctx->d_buckets_snap + (size_t)slot * BKT_WORDS * NB, (size_t)BKT_WORDS * NB * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)  // 64-word records (four 16-word coordinate slots) -> the 52 packed words of the ABI
       for (uint32_t t = 0; t < NB; t++)
-        for (uint32_t j = 0; j < PT_WORDS; j++) buckets[(size_t)t * PT_WORDS + j] = tmp[(size_t)j * NB + t];
+        for (uint32_t c = 0; c < 4; c++)
+          for (uint32_t j = 0; j < 13; j++) buckets[(size_t)t * PT_WORDS + c * 13 + j] = tmp[(size_t)t * BKT_WORDS + c * 16 + j];
     free(tmp);
     HIP_TRY(ctx, e);
   }

@@ -41,6 +41,11 @@ class MsmError(RuntimeError):
 
 
 def library_path() -> str:
+    """csrc/libmsm377.so next to this package.  MSM377_LIB points tools/ab_libs.sh at another BUILD of the same
+    library (an A/B of two engine versions on one box); it is never a different implementation."""
+    override = os.environ.get("MSM377_LIB")
+    if override:
+        return os.path.abspath(override)
     here = os.path.dirname(os.path.abspath(__file__))
     return os.path.normpath(os.path.join(here, "..", "csrc", "libmsm377.so"))
 
