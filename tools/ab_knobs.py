@@ -51,6 +51,7 @@ def main():
         eng.set_timing(True)
     ms = [[] for _ in engines]
     acc = [[] for _ in engines]
+    red = [[] for _ in engines]
     for _ in range(args.reps):
         for i, eng in enumerate(engines):
             t0 = time.perf_counter()
@@ -58,8 +59,9 @@ def main():
                 eng.msm_device(d_points.data_ptr(), d_scalars.data_ptr(), n)
             ms[i].append((time.perf_counter() - t0) * 1e3 / args.iters)
             acc[i].append(eng.stage_ms()["accumulate_kernel"])
-    for cfg, m, a in zip(args.configs, ms, acc):
-        print("%-48s median %.4f  min %.4f  acc_kernel %.4f" % (cfg, statistics.median(m), min(m), statistics.median(a)), flush=True)
+            red[i].append(eng.stage_ms()["reduce"])
+    for cfg, m, a, r in zip(args.configs, ms, acc, red):
+        print("%-48s median %.4f  min %.4f  acc_kernel %.4f  reduce %.4f" % (cfg, statistics.median(m), min(m), statistics.median(a), statistics.median(r)), flush=True)
 
 
 if __name__ == "__main__":

@@ -207,7 +207,9 @@ def main():
     s += emit_glv()
     # Fq keeps R = 2^261 (9 steps): q is 253 bits, so the radix already leaves 8 bits of slack for the lazy forms
     s += emit("EdConsts", Q, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D, "GEN_X": ED_GX, "GEN_Y": ED_GY, "TE_2D": 2 * ED_D}, lazy=True)
-    s += emit64("G1Consts64", P, 6, 14, {"TE_2D": 2 * d_, "TE_INV_S": pow(s_, -1, P), "TE_C_OVER_S": c_ * pow(s_, -1, P)})
+    # TO29: a host-format residue (radix 2^384) times this constant is the DEVICE Montgomery form (radix 2^406) as a plain
+    # integer -- the way back for the block inverses of the batched affine conversion (msm377.hip affine_convert_finish)
+    s += emit64("G1Consts64", P, 6, 14, {"TE_2D": 2 * d_, "TE_INV_S": pow(s_, -1, P), "TE_C_OVER_S": c_ * pow(s_, -1, P), "TO29": 1 << (29 * 14 - 64 * 6)})
     s += emit64("EdConsts64", Q, 4, 9, {"ED_D": ED_D, "ED_2D": 2 * ED_D})
     s += "}  // namespace msm377\n"
     with open(dst, "w") as f:

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Per-launch timeline of the LAST MSM of a short bench run under rocprofv3 --kernel-trace (durations under the profiler's
+# clock).  usage: tools/trace_one_msm.sh <tag> [ENV=VAL ...]
+tag=$1; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+cd /tmp && export TMPDIR=/tmp
+env "$@" true
+for kv in "$@"; do export "$kv"; done
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find $out -name "*kernel_trace.csv" | head -1)
+python3 - "$f" <<PY
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+idx=[i for i,r in enumerate(rows) if "k_decompose" in r["Kernel_Name"]][-1]
+t0=int(rows[idx]["Start_Timestamp"])
+for r in rows[max(0,idx-4):]:
+    s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
+    name=r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ","")
+    print("%8.1f .. %8.1f us  dur %7.1f  %s" % ((s-t0)/1000,(e-t0)/1000,(e-s)/1000,name[:70]))
+PY

@@ -296,27 +296,14 @@ struct TeDev {
   }
 };
 
-// Affine twisted Edwards records for RESIDENT bases (fixed-base mode): one field inversion per point at
-// msm377_g1_set_bases time buys 7 instead of 8 products per bucket addition and 160-byte records.  Only the
-// base-facing half of the policy differs; buckets, reduction and tail are TeDev's.
+// Affine twisted Edwards records (the batched conversion k_affine_up / k_affine_down; msm377_g1_msm_device and resident
+// tables): 7 instead of 8 products per bucket addition and 160-byte records.  Only the base-facing half of the policy
+// differs; buckets, reduction and tail are TeDev's.
 struct TeAffBase {
-  static constexpr uint32_t REC_WORDS = 40;  // (y-x)[13] (y+x)[13] (2dxy)[13] pad[1]
-  static constexpr uint32_t RAW_WORDS = 24;
+  static constexpr uint32_t REC_WORDS = 40;  // (y-x)[13] (y+x)[13] (2dxy)[13] pad[1]; written by k_affine_down
   static constexpr int MADD_PRODUCTS = 7;
   using Base = Te377::ABase;
   using Pt = Te377::Ext;
-  static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
-    bool bad;
-    const Base b = Te377::affine_from_wire(raw, raw + 12, bad);
-#pragma unroll
-    for (int j = 0; j < 13; j++) {
-      rec[j] = b.ymx.l[j];
-      rec[13 + j] = b.ypx.l[j];
-      rec[26 + j] = b.kt.l[j];
-    }
-    rec[39] = 0;
-    return bad;
-  }
   static __device__ __forceinline__ Base load_base(const uint32_t* __restrict__ bases, uint32_t idx) {
     uint32_t w[40];
     load_words16(bases + (size_t)idx * REC_WORDS, w, 10);
@@ -391,6 +378,13 @@ __device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t 
 
 // ------------------------------------------------------------------------ kernels ----
 
+// Zeroes a few words (error words, work-list counters).  A kernel, not hipMemsetAsync: the runtime's fill kernel took
+// 8-18 us per call in the kernel trace (profiles/r02_*), three of them in front of every MSM.
+__global__ void __launch_bounds__(256) k_clear_words(uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {
+  for (uint32_t i = threadIdx.x; i < na; i += 256) a[i] = 0;
+  for (uint32_t i = threadIdx.x; i < nb; i += 256) b[i] = 0;
+}
+
 // One thread per point: wire record (96 bytes G1, 64 bytes Edwards) -> 128-byte Montgomery record.
 template <class CV>  // CV: a curve policy or a base policy (RAW_WORDS, REC_WORDS, convert)
 __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restrict__ raw, uint32_t* __restrict__ bases, uint64_t n, int* __restrict__ err) {
@@ -403,6 +397,155 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restric
   uint4* dst = reinterpret_cast<uint4*>(bases + i * CV::REC_WORDS);
 #pragma unroll
   for (int k = 0; k < (int)CV::REC_WORDS / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// ---- batched conversion to AFFINE twisted Edwards records (7-product bucket additions) ----
+//
+// An affine record needs 1 / Z_i per point (Z_i = v (u + 1), te377.hpp); a Fermat inversion each is ~450 products, so
+// the inverses come from ONE inversion by Montgomery's trick, arranged for width instead of depth:
+//   k_affine_up    a thread walks its AFF_K points (numerators N1, N2, denominator Z, running product C of the Z's --
+//                  all four go to a stash in HBM, which idles during this phase), a product tree in LDS multiplies the
+//                  thread totals of the workgroup (AFF_BLOCK_POINTS points), the tree goes to HBM as well and its root
+//                  to the host, in the host's field format
+//   host           inverts the n / AFF_BLOCK_POINTS block products (Montgomery's trick again, on the tail threads: one
+//                  Fermat inversion per thread, ~25 us, instead of 0.5 ms of serial squarings on one GPU wave)
+//   k_affine_down  walks the stored tree down with the block inverse (a node's inverse = its parent's times its
+//                  sibling's product), then each thread unfolds its points backwards from the stash and writes the
+//                  160-byte records
+// 15 field products per point against 6 for the projective record -- spent while the VALUs idle anyway (the conversion
+// runs on the side stream beside decomposition and the sort, which are HBM / LDS bound) -- and it takes one product
+// off each of the 16 bucket additions the point takes part in.  (A first version kept two points per thread in
+// registers and recomputed instead of stashing: 17 products per point, but most of them in tree levels with idle
+// lanes -- 0.63 ms, longer than the sort it was meant to hide under.)  Points the Edwards model cannot represent
+// (Z = 0: order 2 or 4) enter the product as 1 and raise ERR_TE_CONVERT.
+constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
+constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running product): 13 limbs each, 208 bytes per point
+
+__device__ __forceinline__ void put13(uint32_t* w, const Fp::El& e) {
+#pragma unroll
+  for (int j = 0; j < 13; j++) w[j] = e.l[j];
+}
+__device__ __forceinline__ Fp::El get13(const uint32_t* w) {
+  Fp::El e;
+#pragma unroll
+  for (int j = 0; j < 13; j++) e.l[j] = w[j];
+  return e;
+}
+// Heap-shaped product tree over the workgroup's thread totals: leaves at AFF_THREADS + tid, root at 1, 13 words a node.
+__global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(const uint32_t* __restrict__ raw, uint64_t n, uint32_t* __restrict__ stash,
+                                                              uint32_t* __restrict__ trees, uint32_t* __restrict__ block_prod, uint32_t* __restrict__ host_flag, uint32_t* __restrict__ dev_count,
+                                                              int* __restrict__ err) {
+  // block_prod and host_flag live in pinned, coherent HOST memory: the host polls the flag and starts inverting the
+  // moment the last workgroup has delivered (a D2H copy queued behind this kernel took 60 us to get through beside the
+  // sort, and an event wait adds its wake-up latency on top).  Workgroups count themselves in DEVICE memory -- a
+  // system-scope atomic on host memory is a PCIe round trip each, 0.6 ms for 512 of them -- and the last one raises
+  // the flag with a plain store.
+  using K = G1Consts;
+  __shared__ uint32_t tree[2 * AFF_THREADS][13];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * AFF_BLOCK_POINTS + tid;
+  bool bad = false;
+  Fp::El c = Fp::one();
+#pragma unroll 1
+  for (uint32_t j = 0; j < AFF_K; j++) {
+    const uint64_t i = base + (uint64_t)j * AFF_THREADS;
+    if (i >= n) break;
+    uint32_t w[24];
+    load_words16(raw + i * 24, w, 6);
+    const Fp::El xr = Fp::from_words<12>(w), yr = Fp::from_words<12>(w + 12);
+    const Fp::El u = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_SR)), Fp::from_const(K::TE_S));
+    const Fp::El v = Fp::mul(yr, Fp::from_const(K::TE_SR));
+    const Fp::El cu = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_CSR)), Fp::from_const(K::TE_CS));
+    const Fp::El up = Fp::add(u, Fp::one());
+    Fp::El z = Fp::mul(v, up);
+    const Fp::El n1 = Fp::mul(cu, up), n2 = Fp::sub(z, Fp::dbl(v));  // (u - 1) v = (u + 1) v - 2 v
+    if (Fp::is_zero(z)) {
+      bad = true;
+      z = Fp::one();
+    }
+    uint32_t o[AFF_STASH_WORDS];
+    put13(o, n1);
+    put13(o + 13, n2);
+    put13(o + 26, z);
+    put13(o + 39, c);
+    uint4* dst = reinterpret_cast<uint4*>(stash + i * AFF_STASH_WORDS);
+#pragma unroll
+    for (int k = 0; k < (int)AFF_STASH_WORDS / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    c = Fp::mul(c, z);
+  }
+  if (bad) atomicOr(err, ERR_TE_CONVERT);
+  put13(tree[AFF_THREADS + tid], c);
+  for (uint32_t size = AFF_THREADS / 2; size >= 1; size >>= 1) {
+    __syncthreads();
+    if (tid < size) put13(tree[size + tid], Fp::mul(get13(tree[2 * (size + tid)]), get13(tree[2 * (size + tid) + 1])));
+  }
+  __syncthreads();
+  uint32_t* out = trees + (size_t)blockIdx.x * (2 * AFF_THREADS * 13);
+  const uint32_t* flat = &tree[0][0];
+  for (uint32_t k = tid; k < 2 * AFF_THREADS * 13; k += AFF_THREADS) out[k] = flat[k];
+  if (tid == 0) {  // the root in the host's field format (radix 2^384), like the partial records
+    const Fp::El root = Fp::mul(get13(tree[1]), Fp::from_const(K::TO64));
+    uint32_t w[12];
+    Fp::to_words<12>(root, w);
+#pragma unroll
+    for (int j = 0; j < 12; j++) block_prod[(size_t)blockIdx.x * 12 + j] = w[j];
+    __threadfence_system();  // the product is on its way before this workgroup counts itself
+    if (atomicAdd(dev_count, 1u) == gridDim.x - 1) {
+      *dev_count = 0;  // ready for the next conversion
+      __threadfence_system();
+      *reinterpret_cast<volatile uint32_t*>(host_flag) = gridDim.x;
+    }
+  }
+}
+
+// block_inv: 12 words per workgroup, the inverse of its product as a DEVICE Montgomery residue (the host re-bases);
+// read straight from pinned host memory.
+__global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_down(uint64_t n, const uint32_t* __restrict__ stash, const uint32_t* __restrict__ trees,
+                                                                const uint32_t* __restrict__ block_inv, uint32_t* __restrict__ bases) {
+  __shared__ uint32_t tree[2 * AFF_THREADS][13];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t* in = trees + (size_t)blockIdx.x * (2 * AFF_THREADS * 13);
+  uint32_t* flat = &tree[0][0];
+  for (uint32_t k = tid; k < 2 * AFF_THREADS * 13; k += AFF_THREADS) flat[k] = in[k];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t w[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) w[j] = block_inv[(size_t)blockIdx.x * 12 + j];
+    put13(tree[1], Fp::from_words<12>(w));
+  }
+  // downwards: a node's slot turns from the product of its leaves into the inverse of that product
+  for (uint32_t size = 1; size < AFF_THREADS; size <<= 1) {
+    __syncthreads();
+    if (tid < size) {
+      const uint32_t k = size + tid;
+      const Fp::El inv_k = get13(tree[k]), a = get13(tree[2 * k]), b = get13(tree[2 * k + 1]);
+      put13(tree[2 * k], Fp::mul(inv_k, b));
+      put13(tree[2 * k + 1], Fp::mul(inv_k, a));
+    }
+  }
+  __syncthreads();
+  Fp::El inv = get13(tree[AFF_THREADS + tid]);  // 1 / (the product of this thread's Z's)
+  const uint64_t base = (uint64_t)blockIdx.x * AFF_BLOCK_POINTS + tid;
+#pragma unroll 1
+  for (int j = (int)AFF_K - 1; j >= 0; j--) {
+    const uint64_t i = base + (uint64_t)j * AFF_THREADS;
+    if (i >= n) continue;
+    uint32_t w[AFF_STASH_WORDS];
+    load_words16(stash + i * AFF_STASH_WORDS, w, AFF_STASH_WORDS / 4);
+    const Fp::El zi = Fp::mul(inv, get13(w + 39));  // 1 / Z_j = (1 / C_j) C_(j-1)
+    inv = Fp::mul(inv, get13(w + 26));              // 1 / C_(j-1)
+    const Fp::El x = Fp::mul(get13(w), zi), y = Fp::mul(get13(w + 13), zi);
+    const Fp::El ymx = Fp::sub(y, x), ypx = Fp::add(y, x), kt = Fp::mul(Fp::mul(x, y), Fp::from_const(G1Consts::TE_2D));
+    uint32_t o[TeAffBase::REC_WORDS];
+    put13(o, ymx);
+    put13(o + 13, ypx);
+    put13(o + 26, kt);
+    o[39] = 0;
+    uint4* dst = reinterpret_cast<uint4*>(bases + i * TeAffBase::REC_WORDS);
+#pragma unroll
+    for (int k = 0; k < (int)TeAffBase::REC_WORDS / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+  }
 }
 
 // Sort keys: |d| in 0..32768 with the sign carried separately; coarse range = key / 128
@@ -1133,6 +1276,38 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   store_coord<CV>(bucket_ptr<CV>(buckets, ws, x) + q * CV::COORD_WORDS, c.l);
 }
 
+// The last levels of the reduction in ONE launch.  After level L - 1 every window holds L lists of M = NB >> L buckets
+// (list j, created at level j, starts at bucket NB >> (j + 1)) plus the running block [0, M).  Nothing connects the
+// lists any more: each one only has to be summed, and only the running block keeps spawning new lists (levels L..14).
+// So a workgroup of 128 lane quads takes one list -- or the running block with everything it spawns -- through all
+// its remaining levels with a workgroup barrier between levels, instead of one kernel launch per level for the whole
+// grid: (L + 1) workgroups per window, 15 - L barriers each.  Every level of a list halves it in place exactly as
+// k_tree_step_quad does (same bucket pairs, so the partial records come out the same).
+constexpr uint32_t TAIL_THREADS = 512;  // 128 lane quads; 2 waves per SIMD, so an addition may use 256 VGPRs
+template <class CV>
+__global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __restrict__ buckets, uint32_t L, int* __restrict__ err) {
+  const uint32_t ws = blockIdx.y, job = blockIdx.x;  // job < L: list `job`; job == L: the running block
+  const uint32_t q = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  bool bad = false;
+  for (uint32_t r = L; r < TREE_LEVELS; r++) {
+    const uint32_t half = NB >> (r + 1);
+    // lists this workgroup halves at level r: its own one, or the running block (list index 0) and the lists the
+    // block has spawned since level L (created at levels L .. r - 1: list indices L + 1 .. r in k_tree_step's scheme)
+    const uint32_t nlists = job < L ? 1u : 1u + (r - L);
+    for (uint32_t op = quad; op < nlists * half; op += TAIL_THREADS / 4) {
+      const uint32_t li = op / half, kk = op % half;
+      const uint32_t oi = job < L ? job + 1 : (li == 0 ? 0u : L + li);
+      const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
+      const uint32_t x = lo + kk, y = x + half;
+      const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, ws, x), load_bucket<CV>(buckets, ws, y), q);
+      bad |= CV::is_bad(sum);
+      store_coord<CV>(bucket_ptr<CV>(buckets, ws, x) + q * CV::COORD_WORDS, coord4(q, sum).l);
+    }
+    __syncthreads();  // workgroup-scope fence + barrier: the next level reads what this one wrote
+  }
+  if (bad) atomicOr(err, ERR_TE_TREE);
+}
+
 // Quad per split row: bucket += its overflow partials.
 template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
@@ -1344,6 +1519,17 @@ struct msm377_ctx {
   uint32_t* d_row_ovf_base = nullptr; // 16 x NB
   uint32_t* d_split_rows = nullptr;   // 16 x NB
   uint32_t* d_ovf = nullptr;          // overflow partial points, 52 words each (<= 16 cap / SEG)
+  uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
+  uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
+  uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
+  uint32_t* h_aff_inv = nullptr;
+  uint32_t* h_aff_flag = nullptr;     // workgroups of k_affine_up that have delivered their product
+  uint32_t *dm_aff_prod = nullptr, *dm_aff_inv = nullptr, *dm_aff_flag = nullptr;
+  uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
+  hipEvent_t aff_up_done = nullptr;
+  std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
+  bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
+  uint64_t affine_min_points = 1ull << 15;  // below this the conversion's host round trip is not worth it (MSM377_AFFINE_MIN)
   int* d_err = nullptr;               // 2 slots
   // pinned host
   uint32_t* h_partials = nullptr;     // 2 slots
@@ -1363,6 +1549,8 @@ struct msm377_ctx {
   // x windows fit one wave per SIMD (65536 lanes) -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from
   // there on, slower before), 6 for 8, 4 for the 2 windows a rank of an 8-GPU run owns.  MSM377_COOP_FROM forces it (15 = never).
   uint32_t coop_from = 0;
+  // First level of the single-launch tail of the reduction (k_reduce_tail); MSM377_TAIL_FROM, 15 = one launch per level throughout.
+  uint32_t tail_from = 7;  // measured (tools/ab_knobs.py, 2^20): 15: 2.874 ms, 7: 2.842, 6: 2.885, 5: 2.916, 4: 3.062
   // GLV front end of the Weierstrass path: 0 = off (default), 1 = on.  phi(P) = [lambda] P holds only for points of
   // the prime-order subgroup, so it is an opt-in: the caller vouches for the inputs (every protocol use does).
   // Interleaved A/B on one MI355X (tools/ab_knobs.py), Weierstrass plain vs GLV ms per MSM: 2^18 1.39 / 1.24,
@@ -1486,9 +1674,81 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, uint64_t f
   // main stream, so the previous call's readers of d_bases are done.
   if (n == 0) return MSM377_OK;
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
-  if (clear_err) HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
+  if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases + first * CV::REC_WORDS, n,
                      ctx->d_err + 2);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
+  HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
+  return MSM377_OK;
+}
+
+// ---- batched affine conversion, host side (kernels: k_affine_up / k_affine_down) ----
+// Inverses of block products [b0, b1) by Montgomery's trick with one Fermat inversion; results re-based to the device's
+// Montgomery radix (G1Consts64::TO29) as 12 plain words each.
+void invert_block_products(msm377_ctx* ctx, uint32_t b0, uint32_t b1) {
+  if (b0 >= b1) return;
+  Fp64::El* pre = ctx->aff_scratch.data();
+  Fp64::El acc = Fp64::one();
+  for (uint32_t b = b0; b < b1; b++) {
+    pre[b] = acc;
+    acc = Fp64::mul(acc, Fp64::from_words32(ctx->h_aff_prod + (size_t)b * 12));
+  }
+  Fp64::El inv = Fp64::inv(acc);
+  const Fp64::El to29 = Fp64::from_const(G1Consts64::TO29);
+  for (uint32_t b = b1; b-- > b0;) {
+    const Fp64::El mine = Fp64::mul(Fp64::mul(inv, pre[b]), to29);  // a plain integer now: x 2^406 mod p
+    inv = Fp64::mul(inv, Fp64::from_words32(ctx->h_aff_prod + (size_t)b * 12));
+    words_from_fp64(mine, ctx->h_aff_inv + (size_t)b * 12);
+  }
+}
+
+inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POINTS - 1) / AFF_BLOCK_POINTS); }
+
+// Phase 1, queued on the side stream: products up to one value per workgroup, delivered into pinned host memory.
+int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
+  if (n == 0) return MSM377_OK;
+  const uint32_t nblk = affine_blocks(n);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
+  __atomic_store_n(ctx->h_aff_flag, 0u, __ATOMIC_RELEASE);
+  hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
+  hipLaunchKernelGGL(k_affine_up, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, d_raw, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag,
+                     ctx->d_aff_count, ctx->d_err + 2);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->aff_up_done, ctx->stream2));
+  return MSM377_OK;
+}
+
+// Phase 2: waits for phase 1 (the main stream keeps the GPU busy meanwhile), inverts the block products on the tail
+// threads, queues the way down and signals `bases_ready`.
+int affine_convert_finish(msm377_ctx* ctx, const uint32_t*, uint64_t n) {
+  if (n == 0) return MSM377_OK;
+  const uint32_t nblk = affine_blocks(n);
+  // Poll the flag in pinned memory (no runtime calls: they would contend with nothing, but they are not free either);
+  // after 20 ms fall back to the event, which also surfaces a failed kernel.
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spins = 0; __atomic_load_n(ctx->h_aff_flag, __ATOMIC_ACQUIRE) != nblk; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->aff_up_done));
+      break;
+    }
+  }
+  if (__atomic_load_n(ctx->h_aff_flag, __ATOMIC_ACQUIRE) != nblk) {
+    ctx->err = "batched affine conversion: the block products did not arrive";
+    return MSM377_EHIP;
+  }
+  if (nblk >= 32 && ctx->tail_threads > 1) {
+    TailPool& pool = ctx->tail_pool;
+    pool.start();
+    const uint32_t per = (nblk + 3) / 4;
+    for (int k = 0; k < 3; k++) pool.post(k, [ctx, k, per, nblk] { invert_block_products(ctx, std::min(nblk, (uint32_t)(k + 1) * per), std::min(nblk, (uint32_t)(k + 2) * per)); });
+    invert_block_products(ctx, 0, std::min(nblk, per));
+    for (int k = 0; k < 3; k++) pool.wait(k);
+  } else {
+    invert_block_products(ctx, 0, nblk);
+  }
+  hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, ctx->d_bases);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
@@ -1557,7 +1817,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   if (ph.front) {
   // One memset clears this part's work-list counters AND its key_max words (0 = full-width ranges); k_decompose
   // then measures window 15 of the plain front end.
-  HIP_TRY(ctx, hipMemsetAsync(meta_block, 0, (size_t)META_BLOCK_WORDS * 4, st));
+  hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, meta_block, META_BLOCK_WORDS, (uint32_t*)d_err, (ph.clear_err && part == 0) ? 1u : 0u);
   uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
@@ -1652,7 +1912,10 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     if (coop_from == 0)
       for (coop_from = 1; coop_from < TREE_LEVELS && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > 65536; coop_from++) {
       }
-    for (uint32_t r = first_level; r < TREE_LEVELS; r++) {
+    // Levels [0, coop_from): one thread per addition (VALU-bound: 2^18 additions per level at first); [coop_from,
+    // tail_from): one lane quad per addition, one launch per level; [tail_from, 15): k_reduce_tail, one launch.
+    const uint32_t tail_from = CV::HAS_QUAD ? ctx->tail_from : TREE_LEVELS;
+    for (uint32_t r = first_level; r < std::min(tail_from, TREE_LEVELS); r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       bool done = false;
       if constexpr (CV::HAS_QUAD) {
@@ -1663,6 +1926,12 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       }
       if (!done) hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, buckets, r, ops, d_err);
       HIP_TRY(ctx, hipGetLastError());
+    }
+    if constexpr (CV::HAS_QUAD) {
+      if (tail_from < TREE_LEVELS) {
+        hipLaunchKernelGGL(k_reduce_tail<CV>, dim3(tail_from + 1, wc), dim3(TAIL_THREADS), 0, st, buckets, tail_from, d_err);
+        HIP_TRY(ctx, hipGetLastError());
+      }
     }
     hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets,
                        d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc);
@@ -1689,7 +1958,12 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
   const bool whole = ph.front && ph.back;  // the two-stream pipeline only for calls enqueued in one piece
   const uint32_t parts = (whole && ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
-  if (ph.clear_err) HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
+  // the error word is cleared by part 0's first kernel together with its counters -- unless there is no such kernel
+  // (back phase only) or a second part on another stream could raise a bit before that kernel has run
+  const bool clear_here = ph.clear_err && (!ph.front || parts == 2);
+  if (clear_here) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, (uint32_t*)d_err, 1u, (uint32_t*)nullptr, 0u);
+  Phase part_phase = ph;
+  part_phase.clear_err = ph.clear_err && !clear_here;
   PartView pv[2];
   const uint32_t wc0 = parts == 2 ? (wc + 1) / 2 : wc;
   pv[0] = PartView{st, 0, 0, wb, wc0, 0, 0};
@@ -1700,7 +1974,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   }
   ctx->last_parts = parts;
   for (uint32_t p = 0; p < parts; p++) {
-    int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS, ph);
+    int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS, part_phase);
     if (rc) return rc;
   }
   if (!ph.back) return MSM377_OK;
@@ -1755,7 +2029,7 @@ int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool gl
   if (!glv) return convert_bases<G1Dev>(ctx, d_raw, n);
   if (n == 0) return MSM377_OK;
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err + 2, 0, sizeof(int), ctx->stream2));
+  hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_convert_bases_glv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
@@ -1776,7 +2050,10 @@ inline int pick_form(const msm377_ctx* ctx, uint64_t n) { return ctx->g1_form ==
 
 int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) {
   if (form == TABLE_TE) return convert_bases<TeDev>(ctx, d_raw, n);
-  if (form == TABLE_TE_AFFINE) return convert_bases<TeAffBase>(ctx, d_raw, n);
+  if (form == TABLE_TE_AFFINE) {  // resident tables: both phases back to back (the caller waits for the side stream anyway)
+    const int rc = affine_convert_begin(ctx, d_raw, n);
+    return rc ? rc : affine_convert_finish(ctx, d_raw, n);
+  }
   return convert_bases_g1(ctx, d_raw, n, form == TABLE_XYZZ_GLV);
 }
 
@@ -1998,10 +2275,13 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
+  if (const char* e = getenv("MSM377_TAIL_FROM")) ctx->tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
   const uint64_t cap = max_points;
   // The main stream outranks the side stream: the base conversion (VALU-heavy, ~0.2 ms) only has to finish before
   // the accumulation starts, decompose + sort on the main stream are the critical path (k_decompose: 16 us alone,
@@ -2034,6 +2314,20 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * BKT_WORDS * 4);
+  const size_t aff_blocks = (size_t)affine_blocks(cap) + 1;
+  dalloc((void**)&ctx->d_aff_count, 64);
+  ok = ok && hipMemset(ctx->d_aff_count, 0, 64) == hipSuccess;
+  dalloc((void**)&ctx->d_aff_stash, cap * AFF_STASH_WORDS * 4);
+  dalloc((void**)&ctx->d_aff_trees, aff_blocks * 2 * AFF_THREADS * 13 * 4);
+  const unsigned host_flags = hipHostMallocMapped | hipHostMallocCoherent;
+  ok = ok && hipHostMalloc((void**)&ctx->h_aff_prod, aff_blocks * 48, host_flags) == hipSuccess &&
+       hipHostMalloc((void**)&ctx->h_aff_inv, aff_blocks * 48, host_flags) == hipSuccess &&
+       hipHostMalloc((void**)&ctx->h_aff_flag, 64, host_flags) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&ctx->dm_aff_prod, ctx->h_aff_prod, 0) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&ctx->dm_aff_inv, ctx->h_aff_inv, 0) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&ctx->dm_aff_flag, ctx->h_aff_flag, 0) == hipSuccess &&
+       hipEventCreateWithFlags(&ctx->aff_up_done, hipEventDisableTiming) == hipSuccess;
+  if (ok) ctx->aff_scratch.resize(aff_blocks);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
@@ -2055,12 +2349,16 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_aff_prod) (void)hipHostFree(ctx->h_aff_prod);
+  if (ctx->h_aff_inv) (void)hipHostFree(ctx->h_aff_inv);
+  if (ctx->h_aff_flag) (void)hipHostFree(ctx->h_aff_flag);
+  if (ctx->aff_up_done) (void)hipEventDestroy(ctx->aff_up_done);
   for (int t = 0; t < 4; t++)
     if (ctx->copy_stream[t]) (void)hipStreamDestroy(ctx->copy_stream[t]);
   for (int k = 0; k < 2; k++)
@@ -2092,9 +2390,20 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   ctx->bases_n = 0;
   int form = pick_form(ctx, n);
   // (Queueing the conversion after k_decompose instead was measured: decompose 77 -> 23 us, sort 272 -> 386 us.)
-  rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
-  if (rc) return rc;
-  rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
+  if (form == TABLE_TE && ctx->te_affine_msm && n >= ctx->affine_min_points) {
+    // Affine records (7-product additions) by the batched conversion: its way up is queued now, the host's inversion
+    // and the way down happen from the hook, once decompose .. work list are queued on the main stream.
+    form = TABLE_TE_AFFINE;
+    rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n);
+    if (rc) return rc;
+    ctx->before_accumulate = [ctx, d_points, n]() -> int { return affine_convert_finish(ctx, (const uint32_t*)d_points, n); };
+    rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
+    ctx->before_accumulate = nullptr;
+  } else {
+    rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
+    if (rc) return rc;
+    rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
+  }
   if (rc != RC_TE_FALLBACK) return rc;
   form = TABLE_XYZZ;  // an exceptional case means points outside the prime-order subgroup: never the GLV front end
   rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
