@@ -156,7 +156,17 @@ def side_workload(args, torch, msm, n):
         batch = 64
         d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
         eng.generate_bases_device(0x377, n, d_points.data_ptr())
-        eng.set_bases_device(d_points.data_ptr(), n)
+        t_set = time.perf_counter()
+        # Default: the plain affine table.  The precomputed-window table (MSM377_BENCH_PRECOMPUTE=1) saves the reduction of
+        # 15 windows and most of the host tail, but its 16 x n records (2.7 GB) no longer sit in the 256 MB Infinity Cache
+        # the way the 168 MB table does, and the gathers of the accumulation kernel pay for it: 2.49 vs 2.25 ms per MSM.
+        if os.environ.get("MSM377_BENCH_PRECOMPUTE", "0") == "1":
+            eng.set_bases_precomputed_device(d_points.data_ptr(), n)  # [2^(16 w)] P_i for all windows: one reduction per MSM
+            out["table"] = "precomputed window multiples, 16 x n affine records"
+        else:
+            eng.set_bases_device(d_points.data_ptr(), n)
+            out["table"] = "n affine records"
+        out["set_bases_ms"] = round((time.perf_counter() - t_set) * 1e3, 2)
         # 64 scalar sets: the seeded set rotated by b entries (distinct MSMs, no 2 GB of host bignum work)
         d_one = torch.frombuffer(bytearray(scalars_host), dtype=torch.uint8).cuda().view(n, 32)
         d_scalars = torch.cat([torch.roll(d_one, shifts=b, dims=0) for b in range(batch)]).contiguous().view(-1)

@@ -82,6 +82,13 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
 /* Fixed-base batches (BASELINE.json config 5): convert and keep a base set in HBM once ... */
 int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
 int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n);
+/* The same with precomputed window multiples (BASELINE.json config 5, "precomputed-point reuse"): additionally keeps
+ * [2^(16 w)] P_i for all 16 windows (16 n affine records: 2.7 GB at n = 2^20, allocated on demand, ~45 ms once).  Every
+ * window then gathers points that already carry its weight, so the sixteen bucket sets are simply added together on the
+ * GPU: ONE bucket reduction, one partial record and a 16-step host tail per MSM instead of 16 and 256.  Results are
+ * identical.  In the Weierstrass form (msm377_ctx_set_g1_form 0) this is msm377_g1_set_bases. */
+int msm377_g1_set_bases_precomputed(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
+int msm377_g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint64_t n);
 /* ... then run any number of MSMs of n scalars (host or device pointer) against it. */
 int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]);
 int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint8_t out_xy[96]);

@@ -415,6 +415,42 @@ def test_argument_errors(engine, golden):
     assert e.value.code == -1
 
 
+def test_fixed_base_with_precomputed_window_multiples(engine, oracle):
+    """BASELINE.json config 5 ("precomputed-point reuse"): the resident table keeps [2^(16 w)] P_i for every window, the
+    sixteen bucket sets are added on the GPU, one reduction and a 16-step tail follow.  Same results as the oracle:
+    single calls, a prefix of the bases, batches, and inputs that make the Edwards form fall back."""
+    n = 3000
+    pts, _ = seeded_inputs(oracle, n, 55)
+    engine.set_bases_precomputed(pts)
+    for s_ in range(3):
+        ks = R.encode_scalars(R.rand_scalars(700 + s_, n))
+        assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
+    ks = R.encode_scalars(R.rand_scalars(2, 100))  # a prefix of the bases
+    assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts[: 96 * 100], ks)
+    sets = [R.encode_scalars(R.rand_scalars(40 + b, n)) for b in range(5)]
+    d_s = dev(b"".join(sets))
+    assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 5) == [util.oracle_msm(oracle, pts, k) for k in sets]
+    # edge scalars: 0, 1, r - 1, digits at the window boundaries
+    pl = R.decode_points(pts)[:8]
+    full = lambda d: sum((d & 0xFFFF) << (16 * w) for w in range(15))  # noqa: E731
+    kl = [0, 1, R.R_ORDER - 1, full(0x8000), full(0x7FFF), full(0xFFFF) % R.R_ORDER, 2, (1 << 252) + 5]
+    engine.set_bases_precomputed(R.encode_points(pl))
+    assert engine.msm_fixed_base(R.encode_scalars(kl)) == R.encode_result(R.msm_naive(pl, kl))
+    # a point outside the prime-order subgroup somewhere in the table: conversion or a doubling flags it, the table
+    # is rebuilt in Weierstrass form and the result is still exact
+    tp = util.t_prime()
+    pl2 = pl[:5] + [R.add(pl[5], tp), (R.P - 1, 0)]
+    kl2 = R.rand_scalars(9, len(pl2))
+    engine.set_bases_precomputed(R.encode_points(pl2))
+    before, _ = engine.fallback_info()
+    assert engine.msm_fixed_base(R.encode_scalars(kl2)) == R.encode_result(R.msm_naive(pl2, kl2))
+    assert engine.fallback_info()[0] == before + 1
+    engine.msm(pts[:96], ks[:32])  # a plain MSM invalidates the resident set
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm_fixed_base(ks)
+    assert e.value.code == -5
+
+
 def test_fixed_base_batches(engine, oracle):
     """BASELINE.json config 5 in small: bases converted once and kept in HBM, several scalar sets."""
     n = 3000

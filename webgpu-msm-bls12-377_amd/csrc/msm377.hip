@@ -431,8 +431,43 @@ __device__ __forceinline__ Fp::El get13(const uint32_t* w) {
   for (int j = 0; j < 13; j++) e.l[j] = w[j];
   return e;
 }
+// Where k_affine_up takes point i from: numerators and denominator of its affine Edwards coordinates, x = n1 / z, y = n2 / z.
+struct AffWireSource {  // wire format (x || y, canonical Weierstrass coordinates): the map of te377.hpp
+  const uint32_t* raw;
+  __device__ __forceinline__ bool load(uint64_t i, Fp::El& n1, Fp::El& n2, Fp::El& z) const {
+    using K = G1Consts;
+    uint32_t w[24];
+    load_words16(raw + i * 24, w, 6);
+    const Fp::El xr = Fp::from_words<12>(w), yr = Fp::from_words<12>(w + 12);
+    const Fp::El u = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_SR)), Fp::from_const(K::TE_S));
+    const Fp::El v = Fp::mul(yr, Fp::from_const(K::TE_SR));
+    const Fp::El cu = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_CSR)), Fp::from_const(K::TE_CS));
+    const Fp::El up = Fp::add(u, Fp::one());
+    z = Fp::mul(v, up);
+    n1 = Fp::mul(cu, up);
+    n2 = Fp::sub(z, Fp::dbl(v));  // (u - 1) v = (u + 1) v - 2 v
+    return Fp::is_zero(z);
+  }
+};
+struct AffDoublingSource {  // [2^16] of the point in an affine record of the previous window's table (precomputed-window tables)
+  const uint32_t* prev;
+  __device__ __forceinline__ bool load(uint64_t i, Fp::El& n1, Fp::El& n2, Fp::El& z) const {
+    Te377::Ext p = Te377::from_base_affine(TeAffBase::load_base(prev, (uint32_t)i), false);
+    bool bad = false;
+#pragma unroll 1
+    for (int k = 0; k < MSM377_WINDOW_BITS; k++) {
+      p = Te377::add(p, p);  // the unified law doubles
+      bad |= Te377::is_bad(p);
+    }
+    n1 = Fp::canon(p.x);
+    n2 = Fp::canon(p.y);
+    z = Fp::canon(p.z);
+    return bad;
+  }
+};
 // Heap-shaped product tree over the workgroup's thread totals: leaves at AFF_THREADS + tid, root at 1, 13 words a node.
-__global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(const uint32_t* __restrict__ raw, uint64_t n, uint32_t* __restrict__ stash,
+template <class SRC>
+__global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t n, uint32_t* __restrict__ stash,
                                                               uint32_t* __restrict__ trees, uint32_t* __restrict__ block_prod, uint32_t* __restrict__ host_flag, uint32_t* __restrict__ dev_count,
                                                               int* __restrict__ err) {
   // block_prod and host_flag live in pinned, coherent HOST memory: the host polls the flag and starts inverting the
@@ -450,16 +485,8 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(const uint32_t* __
   for (uint32_t j = 0; j < AFF_K; j++) {
     const uint64_t i = base + (uint64_t)j * AFF_THREADS;
     if (i >= n) break;
-    uint32_t w[24];
-    load_words16(raw + i * 24, w, 6);
-    const Fp::El xr = Fp::from_words<12>(w), yr = Fp::from_words<12>(w + 12);
-    const Fp::El u = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_SR)), Fp::from_const(K::TE_S));
-    const Fp::El v = Fp::mul(yr, Fp::from_const(K::TE_SR));
-    const Fp::El cu = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_CSR)), Fp::from_const(K::TE_CS));
-    const Fp::El up = Fp::add(u, Fp::one());
-    Fp::El z = Fp::mul(v, up);
-    const Fp::El n1 = Fp::mul(cu, up), n2 = Fp::sub(z, Fp::dbl(v));  // (u - 1) v = (u + 1) v - 2 v
-    if (Fp::is_zero(z)) {
+    Fp::El n1, n2, z;
+    if (src.load(i, n1, n2, z)) {
       bad = true;
       z = Fp::one();
     }
@@ -1057,7 +1084,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
                                                        const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into) {
+                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into, uint64_t table_stride) {
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v == 0 && *conv_err) atomicOr(err, *conv_err);  // the table holds a point its coordinate system cannot represent
   if (v >= *work_total) return;
@@ -1065,6 +1092,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   const uint32_t ws = it.row / NB, t = it.row % NB;
   const uint32_t* rp = row_ptr + (size_t)ws * RP;
   const uint32_t* vi = val_idx + (size_t)ws * n;
+  bases += (size_t)ws * table_stride * BP::REC_WORDS;  // precomputed-window tables: window slot ws gathers from its own copy, [2^(16 ws)] P_i
   const uint32_t row_beg = rp[t + 1], row_end = rp[t + 2];
   const uint32_t seglen = row_split(row_end - row_beg, SEG).seglen;
   uint32_t k = row_beg + it.seg * seglen;
@@ -1072,7 +1100,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   // into: the buckets already hold the sums of an earlier chunk of the same MSM (host-buffer entry point, chunked
   // upload): the row's first item continues from there.
   typename CV::Pt acc = (into && it.seg == 0) ? load_bucket<CV>(buckets, ws, t) : CV::identity();
-  bool start_fresh = !(into && it.seg == 0);
+  const bool start_fresh = !(into && it.seg == 0);
   bool bad = false;  // an exceptional pair of the twisted Edwards law (te377.hpp): sticky, the caller falls back
   if (k < end) {
     // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
@@ -1081,24 +1109,33 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
     uint32_t e_cur = vi[k];
     uint32_t e_nxt = (k + 1 < end) ? vi[k + 1] : 0u;
     typename BP::Base cur = BP::load_base(bases, e_cur & 0x7fffffffu);
-    while (true) {
+    bool more = true;  // cur / e_cur hold an entry that has not been added yet
+    // One stage: start the gathers for the next two entries, add entry `cur`, rotate.  FIRST is a compile-time
+    // switch so that the chain's first entry (BP::first: a copy, one product) is PEELED off the loop -- written as
+    // `start_fresh ? first(cur) : madd(acc, cur)` inside the loop the compiler evaluated both sides every
+    // iteration and selected: 8 products per iteration instead of 7 (9 instead of 8 with projective records; 2697
+    // v_mad_u64_u32 in the loop body instead of 2360 -- tools/isa_mix.py, profiles/r02_final/isa_mix.json).
+    auto stage = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       k++;
-      const bool more = k < end;
+      more = k < end;
       typename BP::Base nxt = cur;
       uint32_t e_nn = 0u;
       if (more) {
         nxt = BP::load_base(bases, e_nxt & 0x7fffffffu);
         if (k + 1 < end) e_nn = vi[k + 1];
       }
-      // the first entry of a chain that starts from the identity needs no addition (BP::first)
-      acc = start_fresh ? BP::first(cur, (e_cur >> 31) != 0) : BP::madd(acc, cur, (e_cur >> 31) != 0);
-      start_fresh = false;
+      if constexpr (FIRST)
+        acc = BP::first(cur, (e_cur >> 31) != 0);
+      else
+        acc = BP::madd(acc, cur, (e_cur >> 31) != 0);
       bad |= CV::is_bad(acc);
-      if (!more) break;
       cur = nxt;
       e_cur = e_nxt;
       e_nxt = e_nn;
-    }
+    };
+    if (start_fresh) stage(std::true_type{});  // a chain that starts from the identity: its first entry needs no addition
+    while (more) stage(std::false_type{});
   }
   if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
   if (it.seg == 0) {
@@ -1169,6 +1206,21 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
   store_bucket<CV>(buckets, ws, x, sum);
 }
 
+// Precomputed-window tables: bucket t of window slot ws += bucket t of slot ws + half (the table of slot ws already
+// carries the weight 2^(16 ws), so the sixteen bucket sets simply add up); log2(16) launches leave the sum in slot 0.
+template <class CV>
+__global__ void __launch_bounds__(256, 2) k_fold_windows(uint32_t* __restrict__ buckets, uint32_t half, int* __restrict__ err) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;  // < half * NB
+  const uint32_t ws = g / NB, t = g % NB;
+  if (ws >= half) return;
+  const typename CV::Pt b = load_bucket<CV>(buckets, ws + half, t);
+  if (CV::is_stored_identity(b)) return;
+  const typename CV::Pt a = load_bucket<CV>(buckets, ws, t);
+  const typename CV::Pt sum = CV::is_stored_identity(a) ? b : CV::add(a, b);
+  if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
+  store_bucket<CV>(buckets, ws, t, sum);
+}
+
 // ---- latency-bound levels: one XYZZ addition per QUAD of lanes ----
 // From level ~5 on a reduction level has fewer additions than the chip has lanes, and its
 // duration is one serial addition (14 field multiplications, ~14 us).  Here four adjacent
@@ -1188,9 +1240,17 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
 template <int K, int NLIMB>
 __device__ __forceinline__ Limbs<NLIMB> quad_bcast(const Limbs<NLIMB>& v) {
   Limbs<NLIMB> r;
+#if defined(MSM377_QUAD_DPP)
+  // Build-time variant for the root-cause hunt (tools/dpp_repro.sh): v_mov_b32_dpp quad_perm:[K,K,K,K].
+  // MSM377_QUAD_DPP = 1: bound_ctrl off, `old` = the lane's own value; 2: bound_ctrl on (reads of disabled lanes give 0).
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+#pragma unroll
+  for (int j = 0; j < NLIMB; j++) r.l[j] = (uint32_t)__builtin_amdgcn_update_dpp((int)v.l[j], (int)v.l[j], ctrl, 0xf, 0xf, MSM377_QUAD_DPP == 2);
+#else
   const int src = (int)(((threadIdx.x & 63u) & ~3u) | (uint32_t)K);
 #pragma unroll
   for (int j = 0; j < NLIMB; j++) r.l[j] = (uint32_t)__shfl((int)v.l[j], src, 64);
+#endif
   return r;
 }
 template <int NLIMB>
@@ -1519,6 +1579,8 @@ struct msm377_ctx {
   uint32_t* d_row_ovf_base = nullptr; // 16 x NB
   uint32_t* d_split_rows = nullptr;   // 16 x NB
   uint32_t* d_ovf = nullptr;          // overflow partial points, 52 words each (<= 16 cap / SEG)
+  uint32_t* d_table = nullptr;        // precomputed-window table: 16 x table_cap affine records, [2^(16 w)] P_i at record w * bases_n + i
+  uint64_t table_cap = 0;
   uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
   uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
   uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
@@ -1529,7 +1591,11 @@ struct msm377_ctx {
   hipEvent_t aff_up_done = nullptr;
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
   bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
-  uint64_t affine_min_points = 1ull << 15;  // below this the conversion's host round trip is not worth it (MSM377_AFFINE_MIN)
+  // Below this the batched conversion does not pay: it costs ~9 more products per point than the projective record and
+  // saves 16, but its two kernels and the host round trip sit in front of the accumulation, which they cannot hide
+  // under the (short) sort of a small input.  Interleaved A/B, projective / affine ms per MSM (tools/ab_knobs.py):
+  // 2^15 0.69 / 0.88, 2^16 0.75 / 0.89, 2^17 0.88 / 0.97, 2^18 1.19 / 1.26, 2^19 1.76 / 1.78, 2^20 2.89 / 2.79.  MSM377_AFFINE_MIN.
+  uint64_t affine_min_points = 1ull << 20;
   int* d_err = nullptr;               // 2 slots
   // pinned host
   uint32_t* h_partials = nullptr;     // 2 slots
@@ -1706,14 +1772,18 @@ void invert_block_products(msm377_ctx* ctx, uint32_t b0, uint32_t b1) {
 inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POINTS - 1) / AFF_BLOCK_POINTS); }
 
 // Phase 1, queued on the side stream: products up to one value per workgroup, delivered into pinned host memory.
-int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
+int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, const uint32_t* prev_window_records = nullptr, bool clear_err = true) {
   if (n == 0) return MSM377_OK;
   const uint32_t nblk = affine_blocks(n);
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   __atomic_store_n(ctx->h_aff_flag, 0u, __ATOMIC_RELEASE);
-  hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
-  hipLaunchKernelGGL(k_affine_up, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, d_raw, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag,
-                     ctx->d_aff_count, ctx->d_err + 2);
+  if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
+  if (prev_window_records)
+    hipLaunchKernelGGL(k_affine_up<AffDoublingSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffDoublingSource{prev_window_records}, n, ctx->d_aff_stash,
+                       ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
+  else
+    hipLaunchKernelGGL(k_affine_up<AffWireSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffWireSource{d_raw}, n, ctx->d_aff_stash, ctx->d_aff_trees,
+                       ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->aff_up_done, ctx->stream2));
   return MSM377_OK;
@@ -1721,7 +1791,7 @@ int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n) {
 
 // Phase 2: waits for phase 1 (the main stream keeps the GPU busy meanwhile), inverts the block products on the tail
 // threads, queues the way down and signals `bases_ready`.
-int affine_convert_finish(msm377_ctx* ctx, const uint32_t*, uint64_t n) {
+int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n) {
   if (n == 0) return MSM377_OK;
   const uint32_t nblk = affine_blocks(n);
   // Poll the flag in pinned memory (no runtime calls: they would contend with nothing, but they are not free either);
@@ -1748,7 +1818,7 @@ int affine_convert_finish(msm377_ctx* ctx, const uint32_t*, uint64_t n) {
   } else {
     invert_block_products(ctx, 0, nblk);
   }
-  hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, ctx->d_bases);
+  hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
@@ -1786,6 +1856,11 @@ struct Phase {
   bool into = false;       // accumulate on top of the buckets of an earlier chunk
   bool back = true;        // bucket reduction, gather, D2H, completion event
   uint64_t base_first = 0; // first record of ctx->d_bases this chunk's indices refer to
+  // Precomputed-window tables (msm377_g1_set_bases_precomputed): window slot ws gathers from record ws * table_stride + i
+  // of `table`, and because the table already carries the 2^(16 ws) weights the 16 bucket sets are ADDED together
+  // before the reduction: one window's reduction, one window's partial record, a 16-step host tail.
+  const uint32_t* table = nullptr;
+  uint64_t table_stride = 0;
 };
 
 struct PartView {
@@ -1811,7 +1886,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   uint32_t* split_rows = ctx->d_split_rows + (size_t)pv.ws0 * NB;
   WorkItem* work = ctx->d_work + pv.work_off;
   uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::BKT_WORDS;
-  const uint32_t* bases = ctx->d_bases + ph.base_first * BP::REC_WORDS;
+  const uint32_t* bases = ph.table ? ph.table : ctx->d_bases + ph.base_first * BP::REC_WORDS;
   uint32_t* meta_block = ctx->d_work_meta + (size_t)part * META_BLOCK_WORDS;  // [work-list counters | key_max[16]]
   uint32_t* key_max = meta_block + (2 * SEG_BINS + 4);
   if (ph.front) {
@@ -1874,16 +1949,16 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       const dim3 grid((unsigned)((max_items + 255) / 256));
       if constexpr (!std::is_same<BP, CV>::value)
         hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
       else if (ctx->acc_occ == 4)
         hipLaunchKernelGGL((k_accumulate<CV, 4>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
       else if (ctx->acc_occ == 3)
         hipLaunchKernelGGL((k_accumulate<CV, 3>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
@@ -1907,6 +1982,15 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   }
   {
     StageTimer t(ctx, MSM377_STAGE_REDUCE, st, part);
+    const uint32_t wc_acc = wc;  // window slots the accumulation filled
+    uint32_t wc = wc_acc;        // window slots left to reduce (shadows the parameter copy on purpose)
+    if (ph.table) {
+      for (uint32_t half = wc_acc / 2; half >= 1; half /= 2) {  // wc_acc = 16: a power of two
+        hipLaunchKernelGGL(k_fold_windows<CV>, dim3(half * NB / 256), dim3(256), 0, st, buckets, half, d_err);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      wc = 1;
+    }
     const uint32_t first_level = 0;
     uint32_t coop_from = ctx->coop_from;
     if (coop_from == 0)
@@ -1915,7 +1999,13 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     // Levels [0, coop_from): one thread per addition (VALU-bound: 2^18 additions per level at first); [coop_from,
     // tail_from): one lane quad per addition, one launch per level; [tail_from, 15): k_reduce_tail, one launch.
     const uint32_t tail_from = CV::HAS_QUAD ? ctx->tail_from : TREE_LEVELS;
-    for (uint32_t r = first_level; r < std::min(tail_from, TREE_LEVELS); r++) {
+    // (Fusing pairs of thread-level levels -- four buckets a quarter-list apart per thread, four additions, three
+    // stores -- halves their HBM traffic and was slower all the same: reduce 0.290 -> 0.310 ms at 2^20, 0.278 -> 0.296
+    // at 2^16.  The first levels are VALU-bound at two waves per SIMD, the later ones cost one addition's latency
+    // per launch; a thread with four serial additions only lengthens that.)
+    const uint32_t single_from = std::min(tail_from, TREE_LEVELS);
+    uint32_t r = first_level;
+    for (; r < single_from; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       bool done = false;
       if constexpr (CV::HAS_QUAD) {
@@ -1957,7 +2047,7 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   int* d_err = ctx->d_err + slot;
   uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
   const bool whole = ph.front && ph.back;  // the two-stream pipeline only for calls enqueued in one piece
-  const uint32_t parts = (whole && ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
+  const uint32_t parts = (whole && ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && !ph.table && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
   // the error word is cleared by part 0's first kernel together with its counters -- unless there is no such kernel
   // (back phase only) or a second part on another stream could raise a bit before that kernel has run
   const bool clear_here = ph.clear_err && (!ph.front || parts == 2);
@@ -1982,7 +2072,8 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     HIP_TRY(ctx, hipEventRecord(ctx->part_join, ctx->stream3));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->part_join, 0));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
+  const uint32_t wc_out = ph.table ? 1u : wc;  // precomputed-window tables fold the windows on the GPU
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc_out * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
                                hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err + slot, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipEventRecord(ctx->done_ev[slot], st));
@@ -2038,7 +2129,8 @@ int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool gl
 }
 
 // What ctx->d_bases holds for the G1 entry points.
-enum TableForm { TABLE_XYZZ = 0, TABLE_XYZZ_GLV = 1, TABLE_TE = 2, TABLE_TE_AFFINE = 3 };
+enum TableForm { TABLE_XYZZ = 0, TABLE_XYZZ_GLV = 1, TABLE_TE = 2, TABLE_TE_AFFINE = 3, TABLE_TE_PRECOMP = 4 };
+inline bool form_is_te(int form) { return form == TABLE_TE || form == TABLE_TE_AFFINE || form == TABLE_TE_PRECOMP; }
 constexpr int RC_TE_FALLBACK = 1;  // internal: an exceptional case of the twisted Edwards law, rerun on the Weierstrass path
 
 // A prefix of a GLV table (records 0..n-1 = the plain points) serves the plain path; the phi half needs all of it.
@@ -2052,7 +2144,7 @@ int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) 
   if (form == TABLE_TE) return convert_bases<TeDev>(ctx, d_raw, n);
   if (form == TABLE_TE_AFFINE) {  // resident tables: both phases back to back (the caller waits for the side stream anyway)
     const int rc = affine_convert_begin(ctx, d_raw, n);
-    return rc ? rc : affine_convert_finish(ctx, d_raw, n);
+    return rc ? rc : affine_convert_finish(ctx, ctx->d_bases, n);
   }
   return convert_bases_g1(ctx, d_raw, n, form == TABLE_XYZZ_GLV);
 }
@@ -2108,9 +2200,14 @@ void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
 // its range (bit 1 of the error word) reruns on the plain 16-window path, whose records 0..n-1 of the table are
 // the plain points either way.
 int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int form, uint8_t out_xy[96]) {
-  if (form == TABLE_TE || form == TABLE_TE_AFFINE) {
+  if (form_is_te(form)) {
+    Phase ph;
+    if (form == TABLE_TE_PRECOMP) {
+      ph.table = ctx->d_table;
+      ph.table_stride = ctx->bases_n;
+    }
     int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0)
-                              : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
+                              : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     if (ctx->h_err[0] & ERR_TE_ANY) {
@@ -2120,7 +2217,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
     rc = finish_windows(ctx, 0);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    const bool bad = te_tail(ctx, ctx->h_partials, out_xy);
+    const bool bad = form == TABLE_TE_PRECOMP ? teh_combine(ctx->h_partials, 1, out_xy) : te_tail(ctx, ctx->h_partials, out_xy);
     time_tail(ctx, t0);
     if (bad) note_fallback(ctx, MSM377_FB_TAIL);
     return bad ? RC_TE_FALLBACK : MSM377_OK;
@@ -2349,7 +2446,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_table};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
@@ -2396,7 +2493,7 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
     form = TABLE_TE_AFFINE;
     rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n);
     if (rc) return rc;
-    ctx->before_accumulate = [ctx, d_points, n]() -> int { return affine_convert_finish(ctx, (const uint32_t*)d_points, n); };
+    ctx->before_accumulate = [ctx, n]() -> int { return affine_convert_finish(ctx, ctx->d_bases, n); };
     rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
     ctx->before_accumulate = nullptr;
   } else {
@@ -2542,7 +2639,7 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
   rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
   if (rc) return rc;
   // raw copy for the (never expected) fallback from the Edwards form: see resident_table_to_weierstrass
-  if ((form == TABLE_TE || form == TABLE_TE_AFFINE) && d_points != ctx->d_raw_points)
+  if (form_is_te(form) && d_points != ctx->d_raw_points)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, d_points, n * 96, hipMemcpyDeviceToDevice, ctx->stream2));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   ctx->bases_n = n;
@@ -2556,6 +2653,46 @@ int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n) {
   int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 96, 0);
   if (rc) return rc;
   return msm377_g1_set_bases_device(ctx, ctx->d_raw_points, n);
+}
+
+// Precomputed-window tables (BASELINE.json config 5 "precomputed-point reuse"; the reference lists precomputation as
+// future work, README.md:558-563): T[w][i] = [2^(16 w)] P_i for the 16 windows, as affine Edwards records.  Window 0
+// is the batched conversion of the input; every further window doubles the previous one 16 times (unified law) and
+// runs through the same batched inversion (k_affine_up<AffDoublingSource> -> host -> k_affine_down).
+int msm377_g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
+  int rc = check_args(ctx, d_points, d_points, n, true);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->g1_form != 1 || n == 0) return msm377_g1_set_bases_device(ctx, d_points, n);  // Weierstrass form: no precomputation
+  if (ctx->table_cap < n) {
+    if (ctx->d_table) (void)hipFree(ctx->d_table);
+    ctx->d_table = nullptr;
+    ctx->table_cap = 0;
+    if (hipMalloc((void**)&ctx->d_table, (size_t)MSM377_NUM_WINDOWS * n * TeAffBase::REC_WORDS * 4) != hipSuccess) {
+      ctx->err = "precomputed-window table: out of device memory";
+      return MSM377_ENOMEM;
+    }
+    ctx->table_cap = n;
+  }
+  for (uint32_t w = 0; w < MSM377_NUM_WINDOWS && rc == MSM377_OK; w++) {
+    uint32_t* mine = ctx->d_table + (size_t)w * n * TeAffBase::REC_WORDS;
+    rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n, w == 0 ? nullptr : mine - (size_t)n * TeAffBase::REC_WORDS, w == 0);
+    if (rc == MSM377_OK) rc = affine_convert_finish(ctx, mine, n);
+  }
+  if (rc) return rc;
+  if (d_points != ctx->d_raw_points) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, d_points, n * 96, hipMemcpyDeviceToDevice, ctx->stream2));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+  ctx->bases_n = n;
+  ctx->bases_form = TABLE_TE_PRECOMP;
+  return MSM377_OK;
+}
+
+int msm377_g1_set_bases_precomputed(msm377_ctx* ctx, const uint8_t* points, uint64_t n) {
+  if (!ctx || n > ctx->cap || (n && !points)) return MSM377_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = h2d_staged(ctx, ctx->d_raw_points, points, n * 96, 0);
+  if (rc) return rc;
+  return msm377_g1_set_bases_precomputed_device(ctx, ctx->d_raw_points, n);
 }
 
 int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint8_t out_xy[96]) {
@@ -2597,15 +2734,21 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t* sc = (const uint32_t*)d_scalars;
   const int form = resident_form(ctx, n);
-  const bool glv = form == TABLE_XYZZ_GLV, te = form == TABLE_TE || form == TABLE_TE_AFFINE;
+  const bool glv = form == TABLE_XYZZ_GLV, te = form_is_te(form);
   const uint32_t W = glv ? GLV_WINDOWS : MSM377_NUM_WINDOWS;
+  Phase table_phase;
+  if (form == TABLE_TE_PRECOMP) {
+    table_phase.table = ctx->d_table;
+    table_phase.table_stride = ctx->bases_n;
+  }
+  const int W_tail = form == TABLE_TE_PRECOMP ? 1 : (int)W;  // window records the host combines per MSM
   std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
   bool te_fallback = false;
   // Software pipeline over the batch: while the GPU runs MSM b, the host finishes MSM b-1
   // (Horner + inversion on the other slot's partial records).
   for (uint32_t b = 0; b <= batch; b++) {
     if (b < batch && !te_fallback) {
-      rc = form == TABLE_TE_AFFINE ? enqueue_windows<TeDev, TeAffBase>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
+      rc = (form == TABLE_TE_AFFINE || form == TABLE_TE_PRECOMP) ? enqueue_windows<TeDev, TeAffBase>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), false, table_phase)
            : te                    ? enqueue_windows<TeDev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
                                    : enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
       if (rc) return rc;
@@ -2628,7 +2771,7 @@ int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars
         return rc;
       }
       if (te) {
-        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1))) {
+        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W_tail, out_xy + (size_t)96 * (b - 1))) {
           te_fallback = true;
           note_fallback(ctx, MSM377_FB_TAIL);
         }

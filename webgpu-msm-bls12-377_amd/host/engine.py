@@ -82,6 +82,8 @@ def load_library():
         "msm377_g1_msm_device": (i32, [vp, vp, vp, u64, vp]),
         "msm377_g1_set_bases": (i32, [vp, u8p, u64]),
         "msm377_g1_set_bases_device": (i32, [vp, vp, u64]),
+        "msm377_g1_set_bases_precomputed": (i32, [vp, u8p, u64]),
+        "msm377_g1_set_bases_precomputed_device": (i32, [vp, vp, u64]),
         "msm377_g1_msm_fixed_base": (i32, [vp, u8p, u64, vp]),
         "msm377_g1_msm_fixed_base_device": (i32, [vp, vp, u64, vp]),
         "msm377_g1_msm_fixed_base_batch_device": (i32, [vp, vp, u64, u32, vp]),
@@ -221,6 +223,16 @@ class MsmEngine:
 
     def set_bases_device(self, d_points: int, n: int):
         self._check(self._lib.msm377_g1_set_bases_device(self._ctx, d_points, int(n)), "msm377_g1_set_bases_device")
+
+    def set_bases_precomputed(self, points: bytes):
+        """Resident bases WITH precomputed window multiples [2^(16 w)] P_i (msm377_g1_set_bases_precomputed): one bucket
+        reduction and a 16-step tail per fixed-base MSM."""
+        if len(points) % 96:
+            raise ValueError("points buffer length must be a multiple of 96")
+        self._check(self._lib.msm377_g1_set_bases_precomputed(self._ctx, bytes(points), len(points) // 96), "msm377_g1_set_bases_precomputed")
+
+    def set_bases_precomputed_device(self, d_points: int, n: int):
+        self._check(self._lib.msm377_g1_set_bases_precomputed_device(self._ctx, d_points, int(n)), "msm377_g1_set_bases_precomputed_device")
 
     def msm_fixed_base(self, scalars: bytes) -> bytes:
         if len(scalars) % 32:
