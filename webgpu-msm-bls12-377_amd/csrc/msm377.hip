@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restric
 // registers and recomputed instead of stashing: 17 products per point, but most of them in tree levels with idle
 // lanes -- 0.63 ms, longer than the sort it was meant to hide under.)  Points the Edwards model cannot represent
 // (Z = 0: order 2 or 4) enter the product as 1 and raise ERR_TE_CONVERT.
-constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
+constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;  // K = 4 (twice the waves, twice the host's share) measured the same
 constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running product): 13 limbs each, 208 bytes per point
 
 __device__ __forceinline__ void put13(uint32_t* w, const Fp::El& e) {
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
 
 // block_inv: 12 words per workgroup, the inverse of its product as a DEVICE Montgomery residue (the host re-bases);
 // read straight from pinned host memory.
-__global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_down(uint64_t n, const uint32_t* __restrict__ stash, const uint32_t* __restrict__ trees,
+__global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, const uint32_t* __restrict__ stash, const uint32_t* __restrict__ trees,
                                                                 const uint32_t* __restrict__ block_inv, uint32_t* __restrict__ bases) {
   __shared__ uint32_t tree[2 * AFF_THREADS][13];
   const uint32_t tid = threadIdx.x;
@@ -1589,6 +1589,8 @@ struct msm377_ctx {
   uint32_t *dm_aff_prod = nullptr, *dm_aff_inv = nullptr, *dm_aff_flag = nullptr;
   uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
   hipEvent_t aff_up_done = nullptr;
+  hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
+  int aff_down_after_sort = 1;        // MSM377_AFF_AFTER_SORT=0: k_affine_down may run beside the sort (A/B knob)
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
   bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
   // Below this the batched conversion does not pay: it costs ~9 more products per point than the projective record and
@@ -1791,7 +1793,7 @@ int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, con
 
 // Phase 2: waits for phase 1 (the main stream keeps the GPU busy meanwhile), inverts the block products on the tail
 // threads, queues the way down and signals `bases_ready`.
-int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n) {
+int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, bool behind_sort = false) {
   if (n == 0) return MSM377_OK;
   const uint32_t nblk = affine_blocks(n);
   // Poll the flag in pinned memory (no runtime calls: they would contend with nothing, but they are not free either);
@@ -1818,6 +1820,9 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n) 
   } else {
     invert_block_products(ctx, 0, nblk);
   }
+  // k_affine_down beside k_local_sort: both take about three times as long as alone (0.25 ms each instead of 0.09 /
+  // 0.15 -- they fight over the memory system), so the way down waits for the sort and then has the GPU to itself.
+  if (behind_sort && ctx->aff_down_after_sort) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->sort_done, 0));
   hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
@@ -1917,6 +1922,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max);
     HIP_TRY(ctx, hipGetLastError());
+    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   }
   {
     StageTimer t(ctx, MSM377_STAGE_ACCUMULATE, st, part);
@@ -2373,6 +2379,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_AFF_AFTER_SORT")) ctx->aff_down_after_sort = atoi(e);
   if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
@@ -2423,7 +2430,8 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
        hipHostGetDevicePointer((void**)&ctx->dm_aff_prod, ctx->h_aff_prod, 0) == hipSuccess &&
        hipHostGetDevicePointer((void**)&ctx->dm_aff_inv, ctx->h_aff_inv, 0) == hipSuccess &&
        hipHostGetDevicePointer((void**)&ctx->dm_aff_flag, ctx->h_aff_flag, 0) == hipSuccess &&
-       hipEventCreateWithFlags(&ctx->aff_up_done, hipEventDisableTiming) == hipSuccess;
+       hipEventCreateWithFlags(&ctx->aff_up_done, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&ctx->sort_done, hipEventDisableTiming) == hipSuccess;
   if (ok) ctx->aff_scratch.resize(aff_blocks);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
@@ -2456,6 +2464,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->h_aff_inv) (void)hipHostFree(ctx->h_aff_inv);
   if (ctx->h_aff_flag) (void)hipHostFree(ctx->h_aff_flag);
   if (ctx->aff_up_done) (void)hipEventDestroy(ctx->aff_up_done);
+  if (ctx->sort_done) (void)hipEventDestroy(ctx->sort_done);
   for (int t = 0; t < 4; t++)
     if (ctx->copy_stream[t]) (void)hipStreamDestroy(ctx->copy_stream[t]);
   for (int k = 0; k < 2; k++)
@@ -2493,7 +2502,7 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
     form = TABLE_TE_AFFINE;
     rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n);
     if (rc) return rc;
-    ctx->before_accumulate = [ctx, n]() -> int { return affine_convert_finish(ctx, ctx->d_bases, n); };
+    ctx->before_accumulate = [ctx, n]() -> int { return affine_convert_finish(ctx, ctx->d_bases, n, true); };
     rc = g1_table_msm(ctx, (const uint32_t*)d_scalars, n, form, out_xy);
     ctx->before_accumulate = nullptr;
   } else {
