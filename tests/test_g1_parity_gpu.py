@@ -55,10 +55,82 @@ def test_compute_msm_entry_point(golden):
     assert msm.compute_msm(b"", b"", False) == {"x": 0, "y": 1}  # submission.ts:93-95
 
 
+@pytest.mark.parametrize("windows", ["narrow", "wide"])
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 257, 1000, 4097, 10007])
-def test_ragged_sizes_against_oracle(engine, oracle, n):
+def test_ragged_sizes_against_oracle(engine, oracle, n, windows):
+    """Both window geometries at every size: 11-bit windows (the small-input path, default up to 2^15 points; the
+    reference's own small-input switch is submission.ts:97) and the 16-bit main path forced onto the same inputs."""
     pts, ks = seeded_inputs(oracle, n, 100 + n)
-    assert engine.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+    engine.set_narrow_max(1 << 16 if windows == "narrow" else 0)
+    try:
+        exp = util.oracle_msm(oracle, pts, ks)
+        assert engine.msm(pts, ks) == exp
+        d_p, d_s = dev(pts), dev(ks)
+        assert engine.msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == exp
+    finally:
+        engine.set_narrow_max()
+
+
+def test_narrow_windows_edge_cases(engine, oracle, golden):
+    """The small-input path (22 signed 11-bit windows + an unsigned top window from bit 242, 2^11 buckets each) on the
+    inputs that stress a recode: every golden vector (edge scalars, cancellations, repeated points), digits at the
+    11-bit window boundaries (+-2^10, 2^10 - 1, 0), scalars of 2^253 and more (their top digit does not fit: the call
+    must rerun on the 16-bit path), one repeated base point, a skewed set that splits rows, and the scalar-overflow
+    error, which must fire exactly as on the main path."""
+    engine.set_narrow_max(1 << 15)
+    try:
+        for name, case in golden.items():
+            if name.startswith("g1_"):
+                assert engine.msm(case["points"], case["scalars"]) == case["expected"], name
+        g = R.G
+        p2 = R.mul(g, 2)
+        pts = [g, g, R.neg(g), p2, R.neg(p2), g, p2, g, p2]
+        full = lambda d: sum((d & 0x7FF) << (11 * w) for w in range(22))  # noqa: E731
+        ks = [full(0x400), full(0x400), full(0x400), full(0x3FF), full(0x3FF), full(1), full(0x7FF), 0, R.R_ORDER - 1]
+        assert engine.msm(R.encode_points(pts), R.encode_scalars(ks)) == R.encode_result(R.msm_naive(pts, ks))
+        big = [(1 << 253) - 1, 1 << 253, (1 << 254) + 5, 1194 << 242, 2047 << 242, 2048 << 242, 12345, 1, R.R_ORDER - 2]
+        assert engine.msm(R.encode_points(pts), R.encode_scalars(big)) == R.encode_result(R.msm_naive(pts, big))
+        n = 3000
+        rep = R.encode_points([R.FIXED_BASE]) * n
+        kr = R.encode_scalars(R.rand_scalars(31338, n))
+        assert engine.msm(rep, kr) == R.encode_result(R.mul(R.FIXED_BASE, sum(R.decode_scalars(kr)) % R.R_ORDER))
+        pl, _ = seeded_inputs(oracle, 2048, 78)
+        same = R.encode_scalars([R.rand_scalars(79, 1)[0]] * 2048)
+        assert engine.msm(pl, same) == util.oracle_msm(oracle, pl, same)
+        case = golden["g1_n1_gen"]
+        for bad in ((1 << 256) - 1, (1 << 255) - (1 << 239)):
+            with pytest.raises(msm.MsmError) as e:
+                engine.msm(case["points"], bad.to_bytes(32, "little"))
+            assert e.value.code == -3
+        def final_carry16(k):  # cuzk/utils.ts:66-109 on 16-bit windows
+            carry = 0
+            for w in range(16):
+                carry = 1 if ((k >> (16 * w)) & 0xFFFF) + carry >= 32768 else 0
+            return carry
+
+        assert final_carry16((1 << 255) - (1 << 239)) == 1 and final_carry16((1 << 256) - 1) == 1
+        for ok in (0x7FFF << 240, (0x7FFF << 240) + (0x7FFF << 224) + 12345, (1 << 255) - (1 << 239) - (1 << 224)):
+            assert final_carry16(ok) == 0
+            assert engine.msm(case["points"], ok.to_bytes(32, "little")) == R.encode_result(R.mul(R.G, ok)), hex(ok)
+        # resident table + small n
+        engine.set_bases(pl)
+        assert engine.msm_fixed_base(same) == util.oracle_msm(oracle, pl, same)
+        # an exceptional pair of the Edwards law meeting at the FIRST reduction level of the narrow geometry
+        # (buckets 0 and 1024 of the unsigned top window), in a bucket chain, and in the tail
+        tp = util.t_prime()
+        p = R.mul(R.G, 4711)
+        q = R.add(p, tp)
+        c = R.mul(R.G, 99)
+        a = R.add(R.mul(c, 1 << 11), tp)
+        from webgpu_msm_bls12_377_amd.host.engine import FB_ACCUMULATE, FB_TAIL, FB_TREE
+
+        for pts2, ks2, where in (([p, q], [1 << 242, 1025 << 242], FB_TREE), ([p, q], [7, 7], FB_ACCUMULATE), ([c, a], [1 << 11, 1], FB_TAIL)):
+            before, _ = engine.fallback_info()
+            assert engine.msm(R.encode_points(pts2), R.encode_scalars(ks2)) == R.encode_result(R.msm_naive(pts2, ks2))
+            count, mask = engine.fallback_info()
+            assert count == before + 1 and mask & where, (ks2, mask)
+    finally:
+        engine.set_narrow_max()
 
 
 def test_2_16_against_reference_sized_oracle(engine, oracle):
@@ -182,6 +254,7 @@ def test_every_check_of_the_edwards_law_fires(engine):
         ("host tail", [c, a], [1 << 16, 1], FB_TAIL),
     ]
     default_path(engine)
+    engine.set_narrow_max(0)  # the bucket placements below are those of the 16-bit geometry
     for name, pts, ks, where in cases:
         exp = R.encode_result(R.msm_naive(pts, ks))
         pb, sb = R.encode_points(pts), R.encode_scalars(ks)
@@ -218,6 +291,7 @@ def test_every_check_of_the_edwards_law_fires(engine):
                 default_path(engine)
         assert msm.combine_partials(b"".join(parts)) == exp, name
         assert engine.combine_partials(b"".join(parts)) == exp, name
+    engine.set_narrow_max()
 
 
 @pytest.mark.parametrize("world", [2, 8])

@@ -326,15 +326,17 @@ struct TeChecked {
 };
 // Same Horner as g1h_combine over Edwards partial records.
 inline bool teh_is_identity(const TeH::Ext& p) { return Fp64::is_zero(p.x) && Fp64::is_zero(Fp64::sub(p.y, p.z)); }
-inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0) {
+// cbits: distance of two windows in bits (16 on the main path, 11 on the narrow-window path for small inputs);
+// planes: bit planes per window record = log2 of its buckets (15 / 11), all inside the same 16-point record.
+inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
   TeH::Ext acc = TeH::identity();
-  for (int b = 16 * num_windows - 1; b >= 0; b--) {
+  for (int b = cbits * num_windows - 1; b >= 0; b--) {
     acc = chk.dbl(acc);
-    const int w = b >> 4, l = b & 15;
+    const int w = b / cbits, l = b % cbits;
     if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
     // identity points cost nothing: the records of a rank that folded its windows (g1_fold_tagged) are mostly that
-    if (l < 15) {
+    if (l < planes) {
       const TeH::Ext p = teh_from_record_words(base + (size_t)(1 + l) * 48);
       if (!teh_is_identity(p)) acc = chk.add(acc, p);
     }
@@ -346,9 +348,9 @@ inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked&
   return acc;
 }
 // false: done; true: an exceptional case of the law (out untouched).
-inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) {
+inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96], int cbits = 16, int planes = 15) {
   TeChecked chk;
-  const TeH::Ext r = teh_horner(partials, num_windows, chk);
+  const TeH::Ext r = teh_horner(partials, num_windows, chk, 0, cbits, planes);
   if (chk.bad) return true;
   teh_to_wire(r, out);
   return false;

@@ -65,10 +65,15 @@ constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by 
 // with one bit per place it can surface, so that tests can tell which check fired (msm377_ctx_get_fallback_info);
 // any of them makes the call rerun on the Weierstrass path.  MSM377_FB_TAIL is raised by the host tail (fp64_host.hpp
 // TeChecked) and never lives in the device word.
-constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2;
+constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2, ERR_NARROW_RANGE = 128;  // 128: a scalar's top digit does not fit the narrow-window path
 constexpr int ERR_TE_EXCEPTIONAL = MSM377_FB_ACCUMULATE, ERR_TE_MERGE = MSM377_FB_MERGE, ERR_TE_TREE = MSM377_FB_TREE, ERR_TE_CONVERT = MSM377_FB_CONVERT;
 constexpr int ERR_TE_ANY = ERR_TE_EXCEPTIONAL | ERR_TE_MERGE | ERR_TE_TREE | ERR_TE_CONVERT;
 constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
+constexpr uint32_t NARROW_BITS = 11;       // digit width of the small-input path ...
+constexpr uint32_t NARROW_LOG = 11;        // ... whose windows have 2^11 buckets (the unsigned top digit needs the room: k_decompose_narrow)
+constexpr uint32_t NARROW_SEG = 8;         // entries per accumulation work item on that path
+constexpr uint32_t NARROW_WINDOWS = 23;    // 22 signed 11-bit windows + the top window from bit 242 on
+constexpr uint32_t MAX_WINDOW_SLOTS = NARROW_WINDOWS > MSM377_NUM_WINDOWS ? NARROW_WINDOWS : MSM377_NUM_WINDOWS;  // partial-record slots
 
 // ------------------------------------------------------------------ device helpers ----
 
@@ -363,17 +368,19 @@ __device__ __forceinline__ void store_record(uint32_t* __restrict__ p, const typ
 #pragma unroll
   for (uint32_t c = 0; c < 4; c++) store_coord<CV>(p + c * CV::COORD_WORDS, w + c * CV::NL);
 }
+// L = log2 of the buckets per window: 15 for the 16-bit windows of the main path, less on the narrow-window path
+// for small inputs (a run-time value in every kernel behind the sort: `geometry` in the host code).
 template <class CV>
-__device__ __forceinline__ uint32_t* bucket_ptr(uint32_t* b, uint32_t ws, uint32_t t) { return b + ((size_t)ws * NB + t) * CV::BKT_WORDS; }
+__device__ __forceinline__ uint32_t* bucket_ptr(uint32_t* b, uint32_t L, uint32_t ws, uint32_t t) { return b + (((size_t)ws << L) + t) * CV::BKT_WORDS; }
 template <class CV>
-__device__ __forceinline__ const uint32_t* bucket_ptr(const uint32_t* b, uint32_t ws, uint32_t t) { return b + ((size_t)ws * NB + t) * CV::BKT_WORDS; }
+__device__ __forceinline__ const uint32_t* bucket_ptr(const uint32_t* b, uint32_t L, uint32_t ws, uint32_t t) { return b + (((size_t)ws << L) + t) * CV::BKT_WORDS; }
 template <class CV>
-__device__ __forceinline__ typename CV::Pt load_bucket(const uint32_t* __restrict__ b, uint32_t ws, uint32_t t) {
-  return load_record<CV>(bucket_ptr<CV>(b, ws, t));
+__device__ __forceinline__ typename CV::Pt load_bucket(const uint32_t* __restrict__ b, uint32_t L, uint32_t ws, uint32_t t) {
+  return load_record<CV>(bucket_ptr<CV>(b, L, ws, t));
 }
 template <class CV>
-__device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t ws, uint32_t t, const typename CV::Pt& r) {
-  store_record<CV>(bucket_ptr<CV>(b, ws, t), r);
+__device__ __forceinline__ void store_bucket(uint32_t* __restrict__ b, uint32_t L, uint32_t ws, uint32_t t, const typename CV::Pt& r) {
+  store_record<CV>(bucket_ptr<CV>(b, L, ws, t), r);
 }
 
 // ------------------------------------------------------------------------ kernels ----
@@ -635,6 +642,107 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ 
   }
   __syncthreads();
   if (threadIdx.x == 0 && top_key_max && wmax > *top_key_max) atomicMax(top_key_max, wmax);
+}
+
+// ---- narrow windows for small inputs (the reference switches to 4-bit windows below
+//      65 536 points, src/submission/submission.ts:97,173-186) ----
+// Below ~2^15 points the 16 x 32 768 buckets of the main path are mostly empty and their reduction -- 15 levels, the
+// first ones streaming 134 MB of identity records -- is most of the call.  With 11-bit windows (23 windows of 2 048
+// buckets) the bucket array shrinks 11-fold and the reduction loses four levels (0.28 -> 0.115 ms); the additions grow
+// from 16 n to 23 n, which a small input does not notice.  Everything behind the sort runs the same kernels with
+// L = 11 as their run-time bucket geometry; decomposition and sort have their own small kernels here.
+
+// One thread per scalar: W windows of c bits.  Windows 0 .. W-2 are signed digits with a carry (|d| <= 2^(c-1)); the TOP
+// window takes everything that is left WITHOUT a carry out, as an unsigned digit: a signed top window would push
+// its carry into one more window whose only digits are 0 and 1 -- a single row holding a seventh of all points,
+// which no segmenting saves on a small input (measured: the merge of that row alone took 2.6 ms at 2^14).  With
+// c = 11 the top window starts at bit 242, so scalars below r (253 bits) leave it digits below 1 195 < 2^L = 2 048;
+// a larger top digit (scalars >= 2^253) raises ERR_NARROW_RANGE and the call reruns on the 16-bit path.  All digits
+// are stored biased by 2^L: d + 2^L in [0, 2^(L+1)).
+// The error condition stays the reference's (cuzk/utils.ts:95-98 throws when the 16-bit recode ends with a carry):
+// the same inputs are rejected whichever window width runs.
+__global__ void __launch_bounds__(256) k_decompose_narrow(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n, uint32_t c,
+                                                          uint32_t L, uint32_t W, int* __restrict__ err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words16(scalars + i * 8, w, 2);
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1u, bias = 1u << L;
+  uint32_t carry = 0;
+  for (uint32_t win = 0; win + 1 < W; win++) {
+    const uint32_t bit = win * c, word = bit >> 5, off = bit & 31;
+    uint32_t v = w[word] >> off;
+    if (off + c > 32 && word + 1 < 8) v |= w[word + 1] << (32 - off);
+    v = (v & mask) + carry;
+    carry = v >= half ? 1u : 0u;
+    const int d = (int)v - (int)(carry << c);  // in [-2^(c-1), 2^(c-1))
+    digits[(size_t)win * n + i] = (uint16_t)(d + (int)bias);
+  }
+  {  // the top window: bits (W - 1) c .. 255, unsigned, no carry out (at most 32 bits wide for the widths in use)
+    const uint32_t bit = (W - 1) * c, word = bit >> 5, off = bit & 31;
+    uint64_t v = w[word] >> off;
+    for (uint32_t k = word + 1, sh = 32 - off; k < 8; k++, sh += 32) v |= (uint64_t)w[k] << sh;
+    v += carry;
+    if (v >= bias) atomicOr(err, ERR_NARROW_RANGE);
+    digits[(size_t)(W - 1) * n + i] = (uint16_t)((uint32_t)(v < bias ? v : 0) + bias);
+  }
+  uint32_t carry16 = 0;
+#pragma unroll
+  for (uint32_t win = 0; win < 16; win++) carry16 = (((w[win >> 1] >> (16 * (win & 1))) & 0xffffu) + carry16) >= 32768u ? 1u : 0u;
+  if (carry16) atomicOr(err, ERR_SCALAR);
+}
+
+// One workgroup per window: counting sort of the window's n <= SMALL_SORT_MAX digits by key |d| in LDS, straight to the
+// CSR form the accumulation reads (row_ptr: 2^L + 2 offsets per window over keys 0 .. 2^L; val_idx: index | sign << 31).
+constexpr uint32_t SMALL_SORT_MAX = 1u << 16;
+constexpr uint32_t SMALL_BINS_MAX = (1u << 12) + 1;  // keys 0 .. 2^L for L <= 12
+__global__ void __launch_bounds__(1024) k_small_sort(const uint16_t* __restrict__ digits, uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx,
+                                                     uint32_t n, uint32_t L) {
+  __shared__ uint32_t bins[SMALL_BINS_MAX + 1];
+  __shared__ uint32_t part[1024];
+  const uint32_t ws = blockIdx.x, tid = threadIdx.x;
+  const uint32_t half = 1u << L, nbins = half + 1;
+  const uint16_t* dg = digits + (size_t)ws * n;
+  for (uint32_t b = tid; b <= nbins; b += 1024) bins[b] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const int d = (int)dg[i] - (int)half;
+    atomicAdd(&bins[d < 0 ? -d : d], 1u);
+  }
+  __syncthreads();
+  // exclusive scan over the bins: each thread owns `per` consecutive bins
+  const uint32_t per = (nbins + 1023) / 1024;
+  uint32_t local = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t b = tid * per + k;
+    if (b < nbins) local += bins[b];
+  }
+  part[tid] = local;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = tid >= off ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - local;
+  uint32_t* rp = row_ptr + (size_t)ws * (half + 2);
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t b = tid * per + k;
+    if (b < nbins) {
+      const uint32_t cnt = bins[b];
+      bins[b] = run;  // becomes the write cursor of the bin
+      rp[b] = run;
+      run += cnt;
+    }
+  }
+  if (tid == 0) rp[nbins] = n;
+  __syncthreads();
+  uint32_t* vi = val_idx + (size_t)ws * n;
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const int d = (int)dg[i] - (int)half;
+    vi[atomicAdd(&bins[d < 0 ? -d : d], 1u)] = i | (d < 0 ? 0x80000000u : 0u);
+  }
 }
 
 // ---- GLV front end (the reference lists it as future work, README.md:562) ----
@@ -979,8 +1087,8 @@ struct WorkItem {
   uint32_t seg;  // entries [seg * seglen, seg * seglen + seglen) of the row, see row_split
 };
 
-__device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr, uint32_t row) {
-  const uint32_t* rp = row_ptr + (size_t)(row / NB) * RP + (row % NB);
+__device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t row) {
+  const uint32_t* rp = row_ptr + (size_t)(row >> L) * ((1u << L) + 2) + (row & ((1u << L) - 1));
   return rp[2] - rp[1];
 }
 
@@ -1005,7 +1113,7 @@ __device__ __forceinline__ RowSplit row_split(uint32_t len, uint32_t SEG) {
 
 // Thread per row, 1024 rows per block: length histogram of its work items (LDS, then one global
 // atomic per bin and block -- the ~60 hot counters serialise, hence the large blocks); rows with more than one item reserve overflow slots and join the split-row list.
-__global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ work_hist,
+__global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ work_hist,
                                                    uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
                                                    uint32_t* __restrict__ split_rows) {
   __shared__ uint32_t lh[SEG_BINS];
@@ -1017,7 +1125,7 @@ __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__
   RowSplit sp = {1, 0, 0};
   uint32_t my_split = 0, my_ovf = 0;
   if (row < rows) {
-    sp = row_split(row_len(row_ptr, row), SEG);
+    sp = row_split(row_len(row_ptr, L, row), SEG);
     atomicAdd(&lh[sp.lastlen], 1u);
     if (sp.nseg > 1) {
       atomicAdd(&lh[sp.seglen], sp.nseg - 1);
@@ -1055,7 +1163,7 @@ __global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ 
 }
 
 // Thread per row again: claims its slots in the sorted work list.
-__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ cursor,
+__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ cursor,
                                                       WorkItem* __restrict__ work) {
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t lbase[SEG_BINS];
@@ -1065,7 +1173,7 @@ __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restric
   RowSplit sp = {0, 0, 0};
   uint32_t rank_full = 0, rank_last = 0;
   if (row < rows) {
-    sp = row_split(row_len(row_ptr, row), SEG);
+    sp = row_split(row_len(row_ptr, L, row), SEG);
     if (sp.nseg > 1) rank_full = atomicAdd(&lh[sp.seglen], sp.nseg - 1);
     rank_last = atomicAdd(&lh[sp.lastlen], 1u);
   }
@@ -1084,13 +1192,13 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
                                                        const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into, uint64_t table_stride) {
+                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into, uint64_t table_stride, uint32_t L) {
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v == 0 && *conv_err) atomicOr(err, *conv_err);  // the table holds a point its coordinate system cannot represent
   if (v >= *work_total) return;
   const WorkItem it = work[v];
-  const uint32_t ws = it.row / NB, t = it.row % NB;
-  const uint32_t* rp = row_ptr + (size_t)ws * RP;
+  const uint32_t ws = it.row >> L, t = it.row & ((1u << L) - 1);
+  const uint32_t* rp = row_ptr + (size_t)ws * ((1u << L) + 2);
   const uint32_t* vi = val_idx + (size_t)ws * n;
   bases += (size_t)ws * table_stride * BP::REC_WORDS;  // precomputed-window tables: window slot ws gathers from its own copy, [2^(16 ws)] P_i
   const uint32_t row_beg = rp[t + 1], row_end = rp[t + 2];
@@ -1099,7 +1207,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
   // into: the buckets already hold the sums of an earlier chunk of the same MSM (host-buffer entry point, chunked
   // upload): the row's first item continues from there.
-  typename CV::Pt acc = (into && it.seg == 0) ? load_bucket<CV>(buckets, ws, t) : CV::identity();
+  typename CV::Pt acc = (into && it.seg == 0) ? load_bucket<CV>(buckets, L, ws, t) : CV::identity();
   const bool start_fresh = !(into && it.seg == 0);
   bool bad = false;  // an exceptional pair of the twisted Edwards law (te377.hpp): sticky, the caller falls back
   if (k < end) {
@@ -1139,7 +1247,7 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   }
   if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
   if (it.seg == 0) {
-    store_bucket<CV>(buckets, ws, t, acc);
+    store_bucket<CV>(buckets, L, ws, t, acc);
   } else {
     store_record<CV>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * CV::BKT_WORDS, acc);
   }
@@ -1151,14 +1259,14 @@ template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
                                                              const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                             int* __restrict__ err) {
+                                                             int* __restrict__ err, uint32_t L) {
   const uint32_t count = counters[0];
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
     const uint32_t row = split_rows[i];
-    const uint32_t len = row_len(row_ptr, row);
+    const uint32_t len = row_len(row_ptr, L, row);
     const uint32_t nseg = row_split(len, SEG).nseg;
-    const uint32_t ws = row / NB, t = row % NB;
-    typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
+    const uint32_t ws = row >> L, t = row & ((1u << L) - 1);
+    typename CV::Pt acc = load_bucket<CV>(buckets, L, ws, t);
     const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::BKT_WORDS;
     bool bad = false;
     for (uint32_t s = 1; s < nseg; s++) {
@@ -1166,7 +1274,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
       bad |= CV::is_bad(acc);
     }
     if (bad) atomicOr(err, ERR_TE_MERGE);
-    store_bucket<CV>(buckets, ws, t, acc);
+    store_bucket<CV>(buckets, L, ws, t, acc);
   }
 }
 
@@ -1186,7 +1294,8 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __r
 
 // One level r of the reduction (see above): (r + 1) lists of NB/2^(r+1) pair-additions.
 template <class CV>
-__global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
+__global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buckets, uint32_t L, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
+  const uint32_t NB = 1u << L;  // buckets per window of this call (shadows the main path's constant)
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   const uint32_t ws = blockIdx.y;
   if (g >= ops_per_window) return;
@@ -1195,30 +1304,31 @@ __global__ void __launch_bounds__(256, 2) k_tree_step(uint32_t* __restrict__ buc
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);  // list of level r' = oi - 1 starts at NB/2^(r'+1)
   const uint32_t x = lo + kk;
   const uint32_t y = x + half;
-  typename CV::Pt a = load_bucket<CV>(buckets, ws, x);
-  typename CV::Pt b = load_bucket<CV>(buckets, ws, y);
+  typename CV::Pt a = load_bucket<CV>(buckets, L, ws, x);
+  typename CV::Pt b = load_bucket<CV>(buckets, L, ws, y);
   // Empty buckets hold the identity exactly as identity() wrote it (the top window of a 253-bit scalar uses a seventh
   // of its buckets; small inputs leave most of every window empty): adjacent lanes see adjacent buckets, so whole
   // waves skip the addition.
   if (CV::is_stored_identity(b)) return;
   const typename CV::Pt sum = CV::is_stored_identity(a) ? b : CV::add(a, b);
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
-  store_bucket<CV>(buckets, ws, x, sum);
+  store_bucket<CV>(buckets, L, ws, x, sum);
 }
 
 // Precomputed-window tables: bucket t of window slot ws += bucket t of slot ws + half (the table of slot ws already
 // carries the weight 2^(16 ws), so the sixteen bucket sets simply add up); log2(16) launches leave the sum in slot 0.
 template <class CV>
-__global__ void __launch_bounds__(256, 2) k_fold_windows(uint32_t* __restrict__ buckets, uint32_t half, int* __restrict__ err) {
+__global__ void __launch_bounds__(256, 2) k_fold_windows(uint32_t* __restrict__ buckets, uint32_t L, uint32_t half, int* __restrict__ err) {
+  const uint32_t NB = 1u << L;
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;  // < half * NB
   const uint32_t ws = g / NB, t = g % NB;
   if (ws >= half) return;
-  const typename CV::Pt b = load_bucket<CV>(buckets, ws + half, t);
+  const typename CV::Pt b = load_bucket<CV>(buckets, L, ws + half, t);
   if (CV::is_stored_identity(b)) return;
-  const typename CV::Pt a = load_bucket<CV>(buckets, ws, t);
+  const typename CV::Pt a = load_bucket<CV>(buckets, L, ws, t);
   const typename CV::Pt sum = CV::is_stored_identity(a) ? b : CV::add(a, b);
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
-  store_bucket<CV>(buckets, ws, t, sum);
+  store_bucket<CV>(buckets, L, ws, t, sum);
 }
 
 // ---- latency-bound levels: one XYZZ addition per QUAD of lanes ----
@@ -1320,7 +1430,8 @@ __device__ __forceinline__ Fq::El coord4(uint32_t q, const EdLazy::Ext& p) { ret
 
 // One reduction level r (same index scheme as k_tree_step) with a quad per addition.
 template <class CV>
-__global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict__ buckets, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
+__global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict__ buckets, uint32_t L, uint32_t r, uint32_t ops_per_window, int* __restrict__ err) {
+  const uint32_t NB = 1u << L;
   const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   const uint32_t g = gid >> 2, q = threadIdx.x & 3;
   const uint32_t ws = blockIdx.y;
@@ -1329,11 +1440,11 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   const uint32_t oi = g / half, kk = g % half;
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
   const uint32_t x = lo + kk, y = x + half;
-  const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, ws, x), load_bucket<CV>(buckets, ws, y), q);
+  const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, L, ws, x), load_bucket<CV>(buckets, L, ws, y), q);
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
   // each lane stores one coordinate
   const typename CV::F::El c = coord4(q, sum);
-  store_coord<CV>(bucket_ptr<CV>(buckets, ws, x) + q * CV::COORD_WORDS, c.l);
+  store_coord<CV>(bucket_ptr<CV>(buckets, L, ws, x) + q * CV::COORD_WORDS, c.l);
 }
 
 // The last levels of the reduction in ONE launch.  After level L - 1 every window holds L lists of M = NB >> L buckets
@@ -1345,23 +1456,24 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
 // k_tree_step_quad does (same bucket pairs, so the partial records come out the same).
 constexpr uint32_t TAIL_THREADS = 512;  // 128 lane quads; 2 waves per SIMD, so an addition may use 256 VGPRs
 template <class CV>
-__global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __restrict__ buckets, uint32_t L, int* __restrict__ err) {
-  const uint32_t ws = blockIdx.y, job = blockIdx.x;  // job < L: list `job`; job == L: the running block
+__global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __restrict__ buckets, uint32_t L, uint32_t first, int* __restrict__ err) {
+  const uint32_t NB = 1u << L;
+  const uint32_t ws = blockIdx.y, job = blockIdx.x;  // job < first: list `job`; job == first: the running block
   const uint32_t q = threadIdx.x & 3, quad = threadIdx.x >> 2;
   bool bad = false;
-  for (uint32_t r = L; r < TREE_LEVELS; r++) {
+  for (uint32_t r = first; r < L; r++) {
     const uint32_t half = NB >> (r + 1);
     // lists this workgroup halves at level r: its own one, or the running block (list index 0) and the lists the
     // block has spawned since level L (created at levels L .. r - 1: list indices L + 1 .. r in k_tree_step's scheme)
-    const uint32_t nlists = job < L ? 1u : 1u + (r - L);
+    const uint32_t nlists = job < first ? 1u : 1u + (r - first);
     for (uint32_t op = quad; op < nlists * half; op += TAIL_THREADS / 4) {
       const uint32_t li = op / half, kk = op % half;
-      const uint32_t oi = job < L ? job + 1 : (li == 0 ? 0u : L + li);
+      const uint32_t oi = job < first ? job + 1 : (li == 0 ? 0u : first + li);
       const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
       const uint32_t x = lo + kk, y = x + half;
-      const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, ws, x), load_bucket<CV>(buckets, ws, y), q);
+      const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, L, ws, x), load_bucket<CV>(buckets, L, ws, y), q);
       bad |= CV::is_bad(sum);
-      store_coord<CV>(bucket_ptr<CV>(buckets, ws, x) + q * CV::COORD_WORDS, coord4(q, sum).l);
+      store_coord<CV>(bucket_ptr<CV>(buckets, L, ws, x) + q * CV::COORD_WORDS, coord4(q, sum).l);
     }
     __syncthreads();  // workgroup-scope fence + barrier: the next level reads what this one wrote
   }
@@ -1373,15 +1485,15 @@ template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
                                                                   const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                                  int* __restrict__ err) {
+                                                                  int* __restrict__ err, uint32_t L) {
   const uint32_t count = counters[0];
   const uint32_t q = threadIdx.x & 3;
   for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {
     const uint32_t row = split_rows[i];
-    const uint32_t len = row_len(row_ptr, row);
+    const uint32_t len = row_len(row_ptr, L, row);
     const uint32_t nseg = row_split(len, SEG).nseg;
-    const uint32_t ws = row / NB, t = row % NB;
-    typename CV::Pt acc = load_bucket<CV>(buckets, ws, t);
+    const uint32_t ws = row >> L, t = row & ((1u << L) - 1);
+    typename CV::Pt acc = load_bucket<CV>(buckets, L, ws, t);
     const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::BKT_WORDS;
     typename CV::Pt nxt = load_record<CV>(src);
     bool bad = false;
@@ -1393,7 +1505,7 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
     }
     if (bad) atomicOr(err, ERR_TE_MERGE);
     const typename CV::F::El c = coord4(q, acc);
-    store_coord<CV>(bucket_ptr<CV>(buckets, ws, t) + q * CV::COORD_WORDS, c.l);
+    store_coord<CV>(bucket_ptr<CV>(buckets, L, ws, t) + q * CV::COORD_WORDS, c.l);
   }
 }
 
@@ -1402,14 +1514,15 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
 // 2^(32 NW32) and written as NW32 little-endian u32 words, so the host does no conversion
 // multiplications.  One thread per (window slot, point, coordinate).
 template <class CV>
-__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t wc) {
+__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t wc, uint32_t L) {
   const uint32_t g = blockIdx.x * 64 + threadIdx.x;
   if (g >= wc * MSM377_G1_PARTIAL_POINTS * 4) return;
   const uint32_t coord = g & 3, pt = (g >> 2) % MSM377_G1_PARTIAL_POINTS, ws = g / (4 * MSM377_G1_PARTIAL_POINTS);
+  if (pt > L) return;  // narrow windows have fewer bit planes; the host tail never reads the unused points
   const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
   typename CV::F::El v;
 #pragma unroll
-  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, ws, x)[coord * CV::COORD_WORDS + j];
+  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, L, ws, x)[coord * CV::COORD_WORDS + j];
   v = CV::F::mul(v, CV::to64());
   uint32_t w[CV::NW32];
   CV::F::template to_words<CV::NW32>(v, w);
@@ -1646,6 +1759,10 @@ struct msm377_ctx {
   uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
   int last_products = 0;        // field products per bucket addition of the last accumulation launch (bench.py's int32-mad roof)
+  // Inputs of at most this many points run the narrow-window path (11-bit windows: 23 x 2048 buckets instead of
+  // 16 x 32768; MSM377_NARROW_MAX, 0 = never).  Interleaved A/B, 16-bit / narrow ms per MSM (tools/ab_knobs.py):
+  // 2^10 0.64 / 0.46, 2^13 0.67 / 0.53, 2^14 0.68 / 0.51, 2^15 0.73 / 0.60, 2^16 0.74 / 0.71.
+  uint64_t narrow_max_points = 1ull << 15;
   uint64_t fallback_count = 0;  // reruns on the Weierstrass path after an exceptional case of the Edwards law
   uint32_t fallback_mask = 0;   // MSM377_FB_* bits of the last one
 };
@@ -1847,7 +1964,7 @@ uint32_t auto_seg(const msm377_ctx* ctx, uint64_t entries, bool glv) {
 constexpr uint32_t META_BLOCK_WORDS = 2 * SEG_BINS + 4 + MSM377_NUM_WINDOWS;  // per pipeline part: work-list counters + key_max words
 constexpr uint64_t PIPELINE_MIN_ENTRIES = 1ull << 21;  // (windows x points) below which a call stays in one part
 
-constexpr size_t SLOT_WORDS = (size_t)MSM377_NUM_WINDOWS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot
+constexpr size_t SLOT_WORDS = (size_t)MAX_WINDOW_SLOTS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot
 
 // Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
 // the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
@@ -1866,6 +1983,11 @@ struct Phase {
   // before the reduction: one window's reduction, one window's partial record, a 16-step host tail.
   const uint32_t* table = nullptr;
   uint64_t table_stride = 0;
+  // Window width of the call: 16 (the main path: 16 windows x 2^15 buckets, the two-level sort) or NARROW_BITS (small
+  // inputs: k_decompose_narrow + k_small_sort, 22 windows x 2^11 buckets); everything behind the sort takes
+  // L = cbits - 1 as a run-time argument.
+  uint32_t cbits = MSM377_WINDOW_BITS;
+  uint32_t bucket_log = MSM377_WINDOW_BITS - 1;  // L: 2^L buckets per window (NARROW_LOG on the small-input path)
 };
 
 struct PartView {
@@ -1879,7 +2001,13 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
                  uint32_t sort_blocks, const Phase& ph) {
   hipStream_t st = pv.st;
   const uint32_t wc = pv.wc, part = pv.part;
-  const uint32_t SEG = auto_seg(ctx, (uint64_t)wc * n, glv);  // per launch: each part must fill the GPU on its own
+  const uint32_t L = ph.bucket_log, NB = 1u << L, RP = NB + 2;  // this call's bucket geometry (shadows the main path's constants)
+  const bool narrow = ph.cbits != MSM377_WINDOW_BITS;
+  static_assert((uint64_t)NARROW_WINDOWS * SMALL_SORT_MAX / NARROW_SEG + NARROW_WINDOWS * (1u << NARROW_LOG) <= (uint64_t)MSM377_NUM_WINDOWS * 32768, "narrow work items fit the work-item buffer");
+  // per launch: each part must fill the GPU on its own.  Narrow windows: a small input is all latency -- a work item is
+  // a serial chain of ~10 us additions -- so its chains are cut at 8 entries (the buffers, sized for 16 windows of
+  // 2^15 rows plus entries / SEG_MIN items, hold the 23 x 2^11 rows and 23 n / 8 items of an input this small easily).
+  const uint32_t SEG = (narrow && !ctx->seg_plain) ? NARROW_SEG : auto_seg(ctx, (uint64_t)wc * n, glv);
   uint16_t* digits = ctx->d_digits + (size_t)pv.ws0 * n;
   uint32_t* range_counts = ctx->d_range_counts + (size_t)part * NRANGE * (MAX_SORT_BLOCKS / 2);
   uint32_t* region_base = ctx->d_region_base + (size_t)pv.ws0 * (NRANGE + 1);
@@ -1901,14 +2029,21 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
-    if (glv)
+    if (narrow)
+      hipLaunchKernelGGL(k_decompose_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, ph.cbits, L, wc, d_err);
+    else if (glv)
       hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n_scalars, pv.wb, wc, d_err);
     else
       hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err, top_key_max);
     HIP_TRY(ctx, hipGetLastError());
   }
 
-  {
+  if (narrow) {
+    StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
+    hipLaunchKernelGGL(k_small_sort, dim3(wc), dim3(1024), 0, st, digits, row_ptr, val_idx, (uint32_t)n, L);
+    HIP_TRY(ctx, hipGetLastError());
+    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
+  } else {
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
     uint32_t chunks = sort_blocks / wc;
     const uint64_t want = (n + 4095) / 4096;  // at least ~4096 elements per block
@@ -1932,11 +2067,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     uint32_t* cursor = meta + SEG_BINS;
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
-    hipLaunchKernelGGL(k_work_hist, dim3(rows / 1024), dim3(1024), 0, st, row_ptr, rows, SEG, work_hist, row_ovf_base, counters, split_rows);
+    hipLaunchKernelGGL(k_work_hist, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, work_hist, row_ovf_base, counters, split_rows);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3(rows / 1024), dim3(1024), 0, st, row_ptr, rows, SEG, cursor, work);
+    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work);
     HIP_TRY(ctx, hipGetLastError());
     const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
     if (ctx->before_accumulate) {  // must run before the wait below is queued: the wait binds to the event's latest record
@@ -1955,30 +2090,30 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       const dim3 grid((unsigned)((max_items + 255) / 256));
       if constexpr (!std::is_same<BP, CV>::value)
         hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
       else if (ctx->acc_occ == 4)
         hipLaunchKernelGGL((k_accumulate<CV, 4>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
       else if (ctx->acc_occ == 3)
         hipLaunchKernelGGL((k_accumulate<CV, 3>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
     bool merged = false;
     if constexpr (CV::HAS_QUAD) {
       if (ctx->merge_quad) {
-        hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? rows / 64 : 4 * MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
-                           row_ovf_base, ovf, SEG, d_err);
+        hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? (rows + 63) / 64 : 4 * MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
+                           row_ovf_base, ovf, SEG, d_err, L);
         merged = true;
       }
     }
     if (!merged)
-      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? rows / 256 : MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
-                         row_ovf_base, ovf, SEG, d_err);
+      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? (rows + 255) / 256 : MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
+                         row_ovf_base, ovf, SEG, d_err, L);
     HIP_TRY(ctx, hipGetLastError());
   }
   }  // ph.front
@@ -1992,45 +2127,44 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     uint32_t wc = wc_acc;        // window slots left to reduce (shadows the parameter copy on purpose)
     if (ph.table) {
       for (uint32_t half = wc_acc / 2; half >= 1; half /= 2) {  // wc_acc = 16: a power of two
-        hipLaunchKernelGGL(k_fold_windows<CV>, dim3(half * NB / 256), dim3(256), 0, st, buckets, half, d_err);
+        hipLaunchKernelGGL(k_fold_windows<CV>, dim3(half * NB / 256), dim3(256), 0, st, buckets, L, half, d_err);
         HIP_TRY(ctx, hipGetLastError());
       }
       wc = 1;
     }
+    const uint32_t levels = L;  // log2 of the buckets per window
     const uint32_t first_level = 0;
     uint32_t coop_from = ctx->coop_from;
     if (coop_from == 0)
-      for (coop_from = 1; coop_from < TREE_LEVELS && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > 65536; coop_from++) {
+      for (coop_from = 1; coop_from < levels && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > 65536; coop_from++) {
       }
     // Levels [0, coop_from): one thread per addition (VALU-bound: 2^18 additions per level at first); [coop_from,
-    // tail_from): one lane quad per addition, one launch per level; [tail_from, 15): k_reduce_tail, one launch.
-    const uint32_t tail_from = CV::HAS_QUAD ? ctx->tail_from : TREE_LEVELS;
+    // tail_from): one lane quad per addition, one launch per level; [tail_from, levels): k_reduce_tail, one launch.
+    const uint32_t tail_from = CV::HAS_QUAD ? std::min(ctx->tail_from, levels) : levels;
     // (Fusing pairs of thread-level levels -- four buckets a quarter-list apart per thread, four additions, three
     // stores -- halves their HBM traffic and was slower all the same: reduce 0.290 -> 0.310 ms at 2^20, 0.278 -> 0.296
     // at 2^16.  The first levels are VALU-bound at two waves per SIMD, the later ones cost one addition's latency
     // per launch; a thread with four serial additions only lengthens that.)
-    const uint32_t single_from = std::min(tail_from, TREE_LEVELS);
-    uint32_t r = first_level;
-    for (; r < single_from; r++) {
+    for (uint32_t r = first_level; r < tail_from; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       bool done = false;
       if constexpr (CV::HAS_QUAD) {
         if (r >= coop_from) {
-          hipLaunchKernelGGL(k_tree_step_quad<CV>, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, buckets, r, ops, d_err);
+          hipLaunchKernelGGL(k_tree_step_quad<CV>, dim3((4 * ops + 255) / 256, wc), dim3(256), 0, st, buckets, L, r, ops, d_err);
           done = true;
         }
       }
-      if (!done) hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, buckets, r, ops, d_err);
+      if (!done) hipLaunchKernelGGL(k_tree_step<CV>, dim3((ops + 255) / 256, wc), dim3(256), 0, st, buckets, L, r, ops, d_err);
       HIP_TRY(ctx, hipGetLastError());
     }
     if constexpr (CV::HAS_QUAD) {
-      if (tail_from < TREE_LEVELS) {
-        hipLaunchKernelGGL(k_reduce_tail<CV>, dim3(tail_from + 1, wc), dim3(TAIL_THREADS), 0, st, buckets, tail_from, d_err);
+      if (tail_from < levels) {
+        hipLaunchKernelGGL(k_reduce_tail<CV>, dim3(tail_from + 1, wc), dim3(TAIL_THREADS), 0, st, buckets, L, tail_from, d_err);
         HIP_TRY(ctx, hipGetLastError());
       }
     }
     hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets,
-                       d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc);
+                       d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc, L);
     HIP_TRY(ctx, hipGetLastError());
   }
   return MSM377_OK;
@@ -2159,16 +2293,16 @@ int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) 
 // 64-step Horner chain of its own (three of them on the pool), and the caller stitches them together top-down with
 // 64 doublings between blocks -- 64 x (dbl + add) + 192 dbl on the critical path instead of 256 x (dbl + add).
 template <class Pt, class HornerFn, class DblFn, class AddFn>
-Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, DblFn dbl, AddFn add) {
-  constexpr int BLOCK = 4;  // windows per block
+Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, DblFn dbl, AddFn add, int num_windows = MSM377_NUM_WINDOWS, int cbits = 16) {
+  const int block = (num_windows + 3) / 4;  // windows per block; the top block (the caller's) may be shorter
   TailPool& pool = ctx->tail_pool;
   pool.start();
   Pt part[3];
-  for (int k = 0; k < 3; k++)  // block k = windows 4k .. 4k+3; block 3 is the caller's
-    pool.post(k, [&part, k, partials, horner] { part[k] = horner(partials + (size_t)k * BLOCK * 16 * 48, BLOCK); });
-  Pt acc = horner(partials + (size_t)3 * BLOCK * 16 * 48, BLOCK);
+  for (int k = 0; k < 3; k++)  // block k = windows k block .. (k + 1) block - 1
+    pool.post(k, [&part, k, partials, horner, block] { part[k] = horner(partials + (size_t)k * block * 16 * 48, block); });
+  Pt acc = horner(partials + (size_t)3 * block * 16 * 48, num_windows - 3 * block);
   for (int k = 2; k >= 0; k--) {
-    for (int i = 0; i < 16 * BLOCK; i++) acc = dbl(acc);
+    for (int i = 0; i < cbits * block; i++) acc = dbl(acc);
     pool.wait(k);
     acc = add(acc, part[k]);
   }
@@ -2177,12 +2311,13 @@ Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, Db
 
 // true: an addition or doubling of the tail hit an exceptional case of the Edwards law (fp64_host.hpp TeChecked;
 // out_xy untouched) -- the caller reruns on the Weierstrass path, exactly as for the GPU-side flag.
-bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
-  if (ctx->tail_threads <= 1) return teh_combine(partials, MSM377_NUM_WINDOWS, out_xy);
+bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows = MSM377_NUM_WINDOWS, int cbits = 16, int planes = 15) {
+  if (ctx->tail_threads <= 1 || num_windows < 8) return teh_combine(partials, num_windows, out_xy, cbits, planes);
+  const int block = (num_windows + 3) / 4;
   TeChecked chk[4];  // one per block chain (three of them on pool threads), chk[3] also covers the stitching
   const TeH::Ext r = tail_horner_mt<TeH::Ext>(
-      ctx, partials, [&chk, partials](const uint32_t* p, int nw) { return teh_horner(p, nw, chk[(p - partials) / (4 * 16 * 48)]); },
-      [&chk](const TeH::Ext& a) { return chk[3].dbl(a); }, [&chk](const TeH::Ext& a, const TeH::Ext& b) { return chk[3].add(a, b); });
+      ctx, partials, [&chk, partials, block, cbits, planes](const uint32_t* p, int nw) { return teh_horner(p, nw, chk[(p - partials) / ((size_t)block * 16 * 48)], 0, cbits, planes); },
+      [&chk](const TeH::Ext& a) { return chk[3].dbl(a); }, [&chk](const TeH::Ext& a, const TeH::Ext& b) { return chk[3].add(a, b); }, num_windows, cbits);
   if (chk[0].bad || chk[1].bad || chk[2].bad || chk[3].bad) return true;
   teh_to_wire(r, out_xy);
   return false;
@@ -2212,21 +2347,41 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       ph.table = ctx->d_table;
       ph.table_stride = ctx->bases_n;
     }
-    int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0)
-                              : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
-    if (ctx->h_err[0] & ERR_TE_ANY) {
-      note_fallback(ctx, (uint32_t)(ctx->h_err[0] & ERR_TE_ANY));
-      return RC_TE_FALLBACK;
+    // Small inputs: narrow windows (k_decompose_narrow); the window-indexed buffers are sized for them too
+    // (msm377_ctx_create: wcap).  Stage read-backs describe the 16-bit geometry.
+    bool narrow = form != TABLE_TE_PRECOMP && n <= ctx->narrow_max_points && n <= SMALL_SORT_MAX && !ctx->capture;
+    for (;;) {
+      uint32_t windows = MSM377_NUM_WINDOWS;
+      int cbits = MSM377_WINDOW_BITS, planes = MSM377_WINDOW_BITS - 1;
+      ph.cbits = MSM377_WINDOW_BITS;
+      ph.bucket_log = MSM377_WINDOW_BITS - 1;
+      if (narrow) {
+        ph.cbits = NARROW_BITS;
+        ph.bucket_log = NARROW_LOG;
+        windows = NARROW_WINDOWS;
+        cbits = NARROW_BITS;
+        planes = NARROW_LOG;
+      }
+      int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, windows, 0, false, ph)
+                                : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, windows, 0, false, ph);
+      if (rc) return rc;
+      HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+      if (narrow && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar >= 2^253: the 16-bit path takes it
+        narrow = false;
+        continue;
+      }
+      if (ctx->h_err[0] & ERR_TE_ANY) {
+        note_fallback(ctx, (uint32_t)(ctx->h_err[0] & ERR_TE_ANY));
+        return RC_TE_FALLBACK;
+      }
+      rc = finish_windows(ctx, 0);
+      if (rc) return rc;
+      auto t0 = std::chrono::steady_clock::now();
+      const bool bad = form == TABLE_TE_PRECOMP ? teh_combine(ctx->h_partials, 1, out_xy) : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes);
+      time_tail(ctx, t0);
+      if (bad) note_fallback(ctx, MSM377_FB_TAIL);
+      return bad ? RC_TE_FALLBACK : MSM377_OK;
     }
-    rc = finish_windows(ctx, 0);
-    if (rc) return rc;
-    auto t0 = std::chrono::steady_clock::now();
-    const bool bad = form == TABLE_TE_PRECOMP ? teh_combine(ctx->h_partials, 1, out_xy) : te_tail(ctx, ctx->h_partials, out_xy);
-    time_tail(ctx, t0);
-    if (bad) note_fallback(ctx, MSM377_FB_TAIL);
-    return bad ? RC_TE_FALLBACK : MSM377_OK;
   }
   if (form == TABLE_XYZZ_GLV) {
     int rc = enqueue_windows<G1Dev>(ctx, d_scalars, n, 0, GLV_WINDOWS, 0, true);
@@ -2379,6 +2534,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_NARROW_MAX")) ctx->narrow_max_points = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_AFF_AFTER_SORT")) ctx->aff_down_after_sort = atoi(e);
   if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
@@ -2405,19 +2561,24 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   dalloc((void**)&ctx->d_raw_points, cap * 96);
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
   dalloc((void**)&ctx->d_bases, 2 * cap * G1Dev::REC_WORDS * 4);  // 128-byte records of P_i and phi(P_i) (GLV front end), or 256-byte twisted Edwards records of P_i
-  dalloc((void**)&ctx->d_digits, cap * 2 * MSM377_NUM_WINDOWS);
+  // (window, point) entries the window-indexed buffers hold: 16 windows of `cap` points, or the 23 windows of the
+  // narrow path over a small input when that is more (small contexts)
+  const uint64_t wcap = std::max<uint64_t>((uint64_t)MSM377_NUM_WINDOWS * cap, (uint64_t)NARROW_WINDOWS * std::min<uint64_t>(cap, SMALL_SORT_MAX));
+  dalloc((void**)&ctx->d_digits, wcap * 2);
   dalloc((void**)&ctx->d_range_counts, (size_t)NRANGE * MAX_SORT_BLOCKS * 4);  // chunks * wc <= MAX_SORT_BLOCKS
   dalloc((void**)&ctx->d_region_base, (size_t)MSM377_NUM_WINDOWS * (NRANGE + 1) * 4);
   dalloc((void**)&ctx->d_sort_temp, cap * MSM377_NUM_WINDOWS * sizeof(SortElem));
   dalloc((void**)&ctx->d_row_ptr, (size_t)MSM377_NUM_WINDOWS * RP * 4);
-  dalloc((void**)&ctx->d_val_idx, cap * 4 * MSM377_NUM_WINDOWS);
+  dalloc((void**)&ctx->d_val_idx, wcap * 4);
   dalloc((void**)&ctx->d_buckets, (size_t)MSM377_NUM_WINDOWS * BKT_WORDS * NB * 4);
-  dalloc((void**)&ctx->d_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES);
-  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * sizeof(WorkItem));
+  dalloc((void**)&ctx->d_partials, (size_t)2 * SLOT_WORDS * 4);
+  // extra work items / overflow slots beyond one per row: entries / SEG_MIN on the main path, entries / NARROW_SEG on the narrow one
+  const uint64_t extra_items = std::max<uint64_t>((uint64_t)MSM377_NUM_WINDOWS * cap / SEG_MIN, (uint64_t)NARROW_WINDOWS * std::min<uint64_t>(cap, SMALL_SORT_MAX) / NARROW_SEG) + 2;
+  dalloc((void**)&ctx->d_work, ((size_t)MSM377_NUM_WINDOWS * NB + extra_items) * sizeof(WorkItem));
   dalloc((void**)&ctx->d_work_meta, (size_t)2 * META_BLOCK_WORDS * 4);  // one block per pipeline part
   dalloc((void**)&ctx->d_row_ovf_base, (size_t)MSM377_NUM_WINDOWS * NB * 4);
   dalloc((void**)&ctx->d_split_rows, (size_t)MSM377_NUM_WINDOWS * NB * 4);
-  dalloc((void**)&ctx->d_ovf, ((size_t)MSM377_NUM_WINDOWS * cap / SEG_MIN + 2) * BKT_WORDS * 4);
+  dalloc((void**)&ctx->d_ovf, (size_t)extra_items * BKT_WORDS * 4);
   const size_t aff_blocks = (size_t)affine_blocks(cap) + 1;
   dalloc((void**)&ctx->d_aff_count, 64);
   ok = ok && hipMemset(ctx->d_aff_count, 0, 64) == hipSuccess;
@@ -2434,7 +2595,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
        hipEventCreateWithFlags(&ctx->sort_done, hipEventDisableTiming) == hipSuccess;
   if (ok) ctx->aff_scratch.resize(aff_blocks);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
-  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * MSM377_NUM_WINDOWS * MSM377_G1_WINDOW_PARTIAL_BYTES) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * SLOT_WORDS * 4) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
   for (int k = 0; ok && k < 2; k++) ok = ok && hipEventCreateWithFlags(&ctx->done_ev[k], hipEventDisableTiming) == hipSuccess;
   for (int s = 0; ok && s < MSM377_NUM_STAGES; s++)
@@ -3011,6 +3172,12 @@ int msm377_ctx_get_fallback_info(const msm377_ctx* ctx, uint64_t* count, uint32_
   if (!ctx) return MSM377_EINVAL;
   if (count) *count = ctx->fallback_count;
   if (last_mask) *last_mask = ctx->fallback_mask;
+  return MSM377_OK;
+}
+
+int msm377_ctx_set_narrow_max(msm377_ctx* ctx, uint64_t max_points) {
+  if (!ctx) return MSM377_EINVAL;
+  ctx->narrow_max_points = max_points;
   return MSM377_OK;
 }
 

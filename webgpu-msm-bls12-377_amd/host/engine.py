@@ -108,6 +108,7 @@ def load_library():
         "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
         "msm377_ctx_get_products_per_addition": (i32, [vp]),
         "msm377_ctx_get_stage_form": (i32, [vp]),
+        "msm377_ctx_set_narrow_max": (i32, [vp, u64]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -349,6 +350,10 @@ class MsmEngine:
     def stage_form(self) -> int:
         """Coordinate system of the captured buckets: 0 = Weierstrass XYZZ, 1 = twisted Edwards (X, Y, T, Z), -1 = none."""
         return int(self._lib.msm377_ctx_get_stage_form(self._ctx))
+
+    def set_narrow_max(self, max_points: int = 1 << 15):
+        """Inputs of at most this many points run with 11-bit windows (msm377_ctx_set_narrow_max; 0 = never)."""
+        self._check(self._lib.msm377_ctx_set_narrow_max(self._ctx, int(max_points)), "msm377_ctx_set_narrow_max")
 
     def set_g1_form(self, form="edwards"):
         """Internal coordinates of the G1 full-MSM entry points: "edwards" / 1 (default, csrc/te377.hpp) or
