@@ -134,6 +134,27 @@ void shim_teh_scalar_mul(const uint32_t* q24, const uint32_t* k8, uint8_t* out96
   }
   teh_to_wire(acc, out96);
 }
+// Host-tail multiplier: the BMI2 / ADX assembly (when the CPU has it) against the portable unsigned __int128 form, on raw
+// 6 x 64-bit operands (any values below 2^384: both forms take the same inputs).  Returns 0 when the CPU lacks ADX.
+int shim_fp64_mul_both(const uint64_t* a6, const uint64_t* b6, uint64_t* out_adx6, uint64_t* out_portable6) {
+  Fp64::El a, b;
+  for (int i = 0; i < 6; i++) {
+    a.v[i] = a6[i];
+    b.v[i] = b6[i];
+  }
+  const Fp64::El rp = Fp64::mul_portable(a, b);
+  for (int i = 0; i < 6; i++) out_portable6[i] = rp.v[i];
+#if defined(MSM377_HAVE_ADX_MUL)
+  if (!host_has_adx()) return 0;
+  uint64_t t[7];
+  mont_mul6_adx(t, a.v, b.v, G1Consts64::MOD, G1Consts64::N0);
+  if (t[6] || Fp64::geq_p(t)) Fp64::sub_p(t);
+  for (int i = 0; i < 6; i++) out_adx6[i] = t[i];
+  return 1;
+#else
+  return 0;
+#endif
+}
 void shim_g1_add(const uint32_t* a52, const uint32_t* b52, uint32_t* out52) { store_xyzz(g1_add(load_xyzz(a52), load_xyzz(b52)), out52); }
 void shim_g1_dbl(const uint32_t* a52, uint32_t* out52) { store_xyzz(g1_dbl(load_xyzz(a52)), out52); }
 // the 64-bit host-tail field through the same curve template

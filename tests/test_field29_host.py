@@ -239,6 +239,30 @@ def test_twisted_edwards_exceptional_inputs_are_flagged(shim):
     assert out.raw == R.encode_result(R.add(r2, qt))
 
 
+def test_adx_multiplier_matches_the_portable_one(shim):
+    """csrc/fp64_host.hpp mont_mul6_adx (mulx + adcx / adox, used by the host tail and the affine conversion's host
+    inversion) against the portable unsigned __int128 multiplier AND Python integers: random operands, operands at and
+    around p, zero, all-ones words."""
+    rnd = random.Random(64)
+    R64 = 1 << 384
+    ri = pow(R64, -1, R.P)
+    special = [0, 1, R.P - 1, R.P - 2, R.P, (1 << 384) - 1, (1 << 376) - 1, 1 << 383, R64 % R.P]
+    cases = [(a, b) for a in special for b in special] + [(rnd.randrange(R.P), rnd.randrange(R.P)) for _ in range(20000)]
+    have_adx = None
+    for a, b in cases:
+        av = (ctypes.c_uint64 * 6)(*[(a >> (64 * i)) & (2**64 - 1) for i in range(6)])
+        bv = (ctypes.c_uint64 * 6)(*[(b >> (64 * i)) & (2**64 - 1) for i in range(6)])
+        oa, op = (ctypes.c_uint64 * 6)(), (ctypes.c_uint64 * 6)()
+        have_adx = shim.shim_fp64_mul_both(av, bv, oa, op)
+        got_p = sum(int(w) << (64 * i) for i, w in enumerate(op))
+        if a < R.P and b < R.P:
+            assert got_p == a * b * ri % R.P, (hex(a), hex(b))
+        if have_adx:
+            assert list(oa) == list(op), (hex(a), hex(b))
+    if not have_adx:
+        pytest.skip("this CPU has no BMI2 / ADX: the portable multiplier is the only one")
+
+
 def test_lazy_bounds_proof():
     """tools/check_lazy_bounds.py: interval replay of the lazy formulas -- no 64-bit column can overflow, no limb
     of a limb-wise subtraction can go negative, results meet the storage invariant."""

@@ -1613,12 +1613,19 @@ struct TailPool {
   std::mutex mu;
   std::condition_variable cv;
   std::function<void()> job[WORKERS];
-  uint64_t posted[WORKERS] = {};           // generation of the last job handed to worker k (under mu)
+  std::atomic<uint64_t> posted[WORKERS];   // generation of the last job handed to worker k (written under mu)
   std::atomic<uint64_t> done[WORKERS];     // generation worker k has finished
+  // Workers asleep on the condition variable take 20-60 us to come back -- as long as their whole job (a 64-step Horner
+  // chain is ~45 us) -- so a call that will need them ARMS the pool when it starts (prewake): the workers wake up
+  // while the GPU computes and poll for their job until the deadline, then go back to sleep.  Costs three spinning
+  // cores for at most `spin_us` per call (MSM377_TAIL_SPIN_US, 0 = never spin).
+  std::atomic<int64_t> armed_until_ns{0};
   bool stop = false, started = false;
   TailPool() {
     for (auto& d : done) d.store(0);
+    for (auto& d : posted) d.store(0);
   }
+  static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   void start() {
     if (started) return;
     started = true;
@@ -1629,9 +1636,16 @@ struct TailPool {
           std::function<void()> f;
           {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || posted[k] != seen; });
+            cv.wait(lk, [&] { return stop || posted[k].load(std::memory_order_relaxed) != seen || now_ns() < armed_until_ns.load(std::memory_order_relaxed); });
             if (stop) return;
-            seen = posted[k];
+            if (posted[k].load(std::memory_order_relaxed) == seen) {  // armed: poll without the lock until the job or the deadline comes
+              lk.unlock();
+              while (posted[k].load(std::memory_order_acquire) == seen && now_ns() < armed_until_ns.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+              lk.lock();
+              if (stop) return;
+              if (posted[k].load(std::memory_order_relaxed) == seen) continue;  // deadline passed: back to sleep
+            }
+            seen = posted[k].load(std::memory_order_relaxed);
             f = job[k];
           }
           f();
@@ -1639,21 +1653,24 @@ struct TailPool {
         }
       });
   }
+  void prewake(int64_t spin_us) {
+    if (spin_us <= 0) return;
+    start();
+    armed_until_ns.store(now_ns() + spin_us * 1000, std::memory_order_relaxed);
+    cv.notify_all();
+  }
+  void disarm() { armed_until_ns.store(0, std::memory_order_relaxed); }
   void post(int k, std::function<void()> f) {
     {
       std::lock_guard<std::mutex> lk(mu);
       job[k] = std::move(f);
-      posted[k]++;
+      posted[k].fetch_add(1, std::memory_order_release);
     }
     cv.notify_all();
   }
   void wait(int k) {  // short: the job is a few tens of microseconds
-    uint64_t want;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      want = posted[k];
-    }
-    while (done[k].load(std::memory_order_acquire) != want) std::this_thread::yield();
+    const uint64_t want = posted[k].load(std::memory_order_acquire);
+    while (done[k].load(std::memory_order_acquire) != want) __builtin_ia32_pause();
   }
   ~TailPool() {
     if (!started) return;
@@ -1661,6 +1678,7 @@ struct TailPool {
       std::lock_guard<std::mutex> lk(mu);
       stop = true;
     }
+    armed_until_ns.store(0);
     cv.notify_all();
     for (auto& t : th)
       if (t.joinable()) t.join();
@@ -1755,6 +1773,10 @@ struct msm377_ctx {
   bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;
   int tail_threads = 4;               // MSM377_TAIL_THREADS=1: single-threaded host tail
+  // MSM377_TAIL_SPIN_US: how long the tail workers poll for their job after a call has armed them (TailPool).  Off by
+  // default: interleaved runs with 0 / 4000 us showed no difference (tail 0.122-0.149 ms either way at 2^14 and 2^20) --
+  // the tail is bound by its ~2 600 serial field multiplications, not by the workers' wake-up.
+  int64_t tail_spin_us = 0;
   int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
   uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
@@ -2340,7 +2362,17 @@ void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
 // hit an exceptional case (the caller reconverts and reruns).  TABLE_XYZZ_GLV: the GLV front end; a scalar outside
 // its range (bit 1 of the error word) reruns on the plain 16-window path, whose records 0..n-1 of the table are
 // the plain points either way.
+// Arms the tail workers for the length of one call (TailPool::prewake); disarmed when the tail is done.
+struct TailArm {
+  msm377_ctx* c;
+  explicit TailArm(msm377_ctx* ctx) : c(ctx) {
+    if (c->tail_threads > 1) c->tail_pool.prewake(c->tail_spin_us);
+  }
+  ~TailArm() { c->tail_pool.disarm(); }
+};
+
 int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int form, uint8_t out_xy[96]) {
+  TailArm arm(ctx);
   if (form_is_te(form)) {
     Phase ph;
     if (form == TABLE_TE_PRECOMP) {
@@ -2531,6 +2563,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
+  if (const char* e = getenv("MSM377_TAIL_SPIN_US")) ctx->tail_spin_us = atoll(e);
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
@@ -2985,6 +3018,7 @@ static int window_partials(msm377_ctx* ctx, const void* d_points, const void* d_
   }
   const size_t bytes = (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->tail_threads > 1) ctx->tail_pool.prewake(ctx->tail_spin_us);  // the combine of the gathered records follows (msm377_g1_combine_partials_ctx disarms)
   if (n == 0) {  // identity partials: ZZ = 0 everywhere
     if (host_out) memset(host_out, 0, bytes);
     if (dev_out) HIP_TRY(ctx, hipMemset(dev_out, 0, bytes));
@@ -3080,6 +3114,10 @@ int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uin
     all_w = all_w && !te;
   }
   int rc = MSM377_OK;
+  struct Disarm {
+    msm377_ctx* c;
+    ~Disarm() { c->tail_pool.disarm(); }
+  } disarm{ctx};
   if (all_te)
     rc = te_tail(ctx, rec, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
   else if (all_w)
