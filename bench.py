@@ -281,10 +281,21 @@ def main():
     backend = os.environ.get("MSM377_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # MSM377_BENCH_FORCE_SHARDED=1 (rehearsal on a one-GPU box, never set by the driver): run the multi-rank code path --
+    # window records left in HBM, RCCL all-gather, host combine -- with ONE rank that owns all 16 windows.
+    force_sharded = world == 1 and os.environ.get("MSM377_BENCH_FORCE_SHARDED") == "1"
+    saved_stdout = None
+    if world > 1 or force_sharded:
         import torch.distributed as dist
 
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line
+        # there, so stdout points at stderr until the warm-up is over.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -313,12 +324,12 @@ def main():
     # selects the Weierstrass XYZZ path behind the GLV front end
     te_single = world == 1 and os.environ.get("MSM377_G1_FORM", "1") != "0"
     glv_single = world == 1 and not te_single and os.environ.get("MSM377_GLV", "0") == "1"
-    sharder = ShardedMsm(rank, world, device=xdev)
+    sharder = ShardedMsm(rank, world, device=xdev, force_collective=force_sharded)
     sharder_glv = ShardedMsm(rank, world, device=xdev, num_windows=8) if use_glv else None
-    resident = world > 1 and backend == "nccl" and not use_glv  # records stay in HBM until the all-gather
+    resident = (world > 1 or force_sharded) and backend == "nccl" and not use_glv  # records stay in HBM until the all-gather
 
     def step():
-        if world == 1:
+        if world == 1 and not force_sharded:
             return eng.msm_device(pp, sp, n)
         if resident:
             return sharder.run_resident(lambda b, c, out_ptr: eng.window_partials_resident(pp, sp, n, b, c, out_ptr), eng.combine_partials)
@@ -338,6 +349,12 @@ def main():
     result = None
     for _ in range(args.warmup):
         result = step()
+    if saved_stdout is not None:
+        if args.warmup == 0:
+            fence()  # brings the communicator up (and its banner out) before stdout returns
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     eng.set_timing(True)
     stage_sum = {}
     fence()
@@ -391,7 +408,7 @@ def main():
                 "coordinates": "twisted Edwards form of G1, extended coordinates (csrc/te377.hpp)" if te_path else "short Weierstrass, XYZZ",
                 "points": "P_i=[a_i]G, a_i=SplitMix64(0x377)",
                 "scalars": "uniform < r, SplitMix64(0x5ca1a5)",
-                "parallelism": ("%s windows sharded over %d GPUs, one RCCL all-gather" % ("8 GLV" if use_glv else "16", world)) if world > 1 else "single GPU",
+                "parallelism": ("%s windows sharded over %d GPUs, one RCCL all-gather" % ("8 GLV" if use_glv else "16", world)) if (world > 1 or force_sharded) else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",

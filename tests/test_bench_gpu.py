@@ -44,6 +44,16 @@ def test_single_gpu_line_and_two_rank_rehearsal():
     assert "sharded over 2 GPUs" in two["config"]["parallelism"]
 
 
+def test_rccl_path_with_one_rank():
+    """The code path the driver's 8-GPU run takes -- msm377_g1_window_partials_resident, all_gather_into_tensor over RCCL
+    straight from the device records, one read-back, msm377_g1_combine_partials_ctx -- rehearsed with ONE rank that owns
+    all 16 windows (this box has one GPU): same result as the single-GPU engine call."""
+    one = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--log-n", "17", "--no-cpu-baseline"])
+    forced = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--log-n", "17", "--no-cpu-baseline"], {"MSM377_BENCH_FORCE_SHARDED": "1"})
+    assert forced["result_x"] == one["result_x"]
+    assert "sharded over 1 GPUs" in forced["config"]["parallelism"]
+
+
 def test_full_benchmarks_sweep_at_2_16(monkeypatch):
     from webgpu_msm_bls12_377_amd.host import full_benchmarks as fb
 

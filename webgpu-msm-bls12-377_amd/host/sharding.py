@@ -32,7 +32,9 @@ class ShardedMsm:
     """sharded_msm with the exchange buffers allocated once (bench.py, services): a pinned host
     staging tensor, a send tensor and a world_size-slot receive tensor on ``device``."""
 
-    def __init__(self, rank: int, world_size: int, group=None, device=None, num_windows: int = NUM_WINDOWS):
+    def __init__(self, rank: int, world_size: int, group=None, device=None, num_windows: int = NUM_WINDOWS, force_collective: bool = False):
+        """``force_collective``: allocate the exchange buffers and issue the collective even for one rank (a rehearsal of
+        the RCCL path on a one-GPU box; a real single-rank run calls the engine's full MSM instead)."""
         import torch
 
         self.rank, self.world, self.group = rank, world_size, group
@@ -41,7 +43,8 @@ class ShardedMsm:
         self.max_count = (num_windows + world_size - 1) // world_size
         self.slot = self.max_count * WINDOW_PARTIAL_BYTES
         self.counts = [windows_for_rank(r, world_size, num_windows)[1] for r in range(world_size)]
-        if world_size > 1:
+        self.force_collective = force_collective
+        if world_size > 1 or force_collective:
             pin = device is not None and str(device).startswith("cuda")
             self.send_host = torch.zeros(self.slot, dtype=torch.uint8, pin_memory=pin)
             self.recv_host = torch.zeros(self.slot * world_size, dtype=torch.uint8, pin_memory=pin)
@@ -83,7 +86,7 @@ class ShardedMsm:
         same verdict) are recomputed through ``rerun_weierstrass`` (same signature; the engine in form 0) and
         exchanged again.
         """
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             raise ValueError("run_resident is the multi-rank path; a single rank calls the engine's full MSM")
         import torch.distributed as dist
 
