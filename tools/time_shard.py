@@ -28,16 +28,17 @@ def main():
     pp, sp = d_points.data_ptr(), d_scalars.data_ptr()
     full = eng.window_partials_device(pp, sp, n, 0, 16)
     for world in (1, 2, 4, 8, 16):
-        b, c = msm.windows_for_rank(0, world)
-        eng.window_partials_device(pp, sp, n, b, c)
-        eng.set_timing(True)
-        t0 = time.perf_counter()
-        for _ in range(args.iters):
+        for rank in sorted({0, world - 1}):  # the first rank, and the one that owns the top window (13 significant bits: long rows)
+            b, c = msm.windows_for_rank(rank, world)
             eng.window_partials_device(pp, sp, n, b, c)
-        ms = (time.perf_counter() - t0) * 1e3 / args.iters
-        st = eng.stage_ms()
-        eng.set_timing(False)
-        print("world %2d: %d windows per rank  %.3f ms  %s" % (world, c, ms, {k: round(v, 3) for k, v in st.items()}), flush=True)
+            eng.set_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(args.iters):
+                eng.window_partials_device(pp, sp, n, b, c)
+            ms = (time.perf_counter() - t0) * 1e3 / args.iters
+            st = eng.stage_ms()
+            eng.set_timing(False)
+            print("world %2d rank %2d: %d windows  %.3f ms  %s" % (world, rank, c, ms, {k: round(v, 3) for k, v in st.items()}), flush=True)
     t0 = time.perf_counter()
     for _ in range(args.iters):
         msm.combine_partials(full)
