@@ -48,6 +48,22 @@ NUM_BUCKETS = 32768
 # the chip-wide peak is the microbenchmark figure at 8 waves/SIMD (profiles/microbench_r01.txt: mad64 33605 Gop/s).
 MADS_PER_FIELD_PRODUCT = 13 * 13 + 14 * 12
 MAD_PEAK_GLANEOPS = 33605.0
+ALU_PEAK_GLANEOPS = 57062.0  # 32-bit add / logic lane-ops per second at 8 waves/SIMD, same file (add32x3)
+
+
+def isa_loop_mix(products):
+    """VALU instructions and v_mad_u64_u32 per bucket addition, counted in the code object's accumulation loop by
+    tools/isa_mix.py (profiles/rNN_*/isa_mix.json, newest first); None when no listing is committed."""
+    prof = os.path.join(ROOT, "profiles")
+    key = {7: "k_accumulate<TeDev,TeAffBase>", 8: "k_accumulate<TeDev>", 10: "k_accumulate<G1Dev>"}.get(products)
+    for tag in sorted(os.listdir(prof), reverse=True) if os.path.isdir(prof) else []:
+        path = os.path.join(prof, tag, "isa_mix.json")
+        if key and os.path.exists(path):
+            with open(path) as f:
+                loop = json.load(f).get(key, {}).get("hottest_loop")
+            if loop:
+                return tag, loop["valu"], loop["v_mad_u64_u32"]
+    return None, None, None
 
 
 def launch_command(gpus, argv, port):
@@ -389,6 +405,13 @@ def main():
         products = eng.accumulate_products()
         lane_mads = NUM_WINDOWS * n * my_windows / nwin * products * MADS_PER_FIELD_PRODUCT
         mad_rate = lane_mads / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        # all VALU issue slots of the loop, each class at its own measured rate: the roof the kernel actually sits under
+        isa_tag, valu_per_add, mads_per_add = isa_loop_mix(products)
+        issue_frac = None
+        if valu_per_add and acc_ms > 0:
+            adds = NUM_WINDOWS * n * my_windows / nwin
+            issue_ms = adds * (mads_per_add / MAD_PEAK_GLANEOPS + (valu_per_add - mads_per_add) / ALU_PEAK_GLANEOPS) / 1e9 * 1e3
+            issue_frac = round(issue_ms / acc_ms, 4)
         out = {
             "metric": "ms per 2^%d BLS12-377 G1 MSM" % args.log_n,
             "value": round(ms_per_step, 4),
@@ -431,6 +454,10 @@ def main():
                     "lane_mads_per_launch": int(lane_mads),
                     "derivation": "%d windows x n additions x %d field products x %d v_mad_u64_u32 (13x13 + 14x12, csrc/field29.hpp); peak = mad64 at 8 waves/SIMD, profiles/microbench_r01.txt"
                     % (my_windows, products, MADS_PER_FIELD_PRODUCT),
+                    # fraction of the kernel's time that pure VALU issue accounts for: (mads / mad rate + other VALU / add rate) per addition
+                    "valu_issue_frac": issue_frac,
+                    "valu_issue_derivation": ("profiles/%s/isa_mix.json: %d VALU instructions per addition in the loop, %d of them v_mad_u64_u32; rates %g / %g G lane-op/s"
+                                              % (isa_tag, valu_per_add, mads_per_add, MAD_PEAK_GLANEOPS, ALU_PEAK_GLANEOPS)) if issue_frac else None,
                 },
             },
             "whole_job_hbm_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 2),
