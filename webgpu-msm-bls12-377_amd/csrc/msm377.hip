@@ -1736,7 +1736,8 @@ struct msm377_ctx {
   hipEvent_t done_ev[2] = {};
   // host-buffer entry points: pinned staging + copy workers (allocated on first use)
   uint8_t* h_stage = nullptr;  // cap x 128 bytes
-  hipStream_t copy_stream[4] = {};
+  hipStream_t copy_stream[8] = {};
+  int h2d_threads = 4;                // copy workers of the host-buffer entry points (MSM377_H2D_THREADS, 1..8)
   // state
   uint64_t bases_n = 0;  // resident base count (fixed-base mode)
   uint64_t last_n = 0;
@@ -1811,7 +1812,8 @@ void note_fallback(msm377_ctx* ctx, uint32_t mask) {
 // for a first hipMemcpy from fresh pageable pages (4.4 ms once the runtime has pinned them) and
 // 3.3 + 2.9 ms for hipHostRegister + copy.  Returns when the data is on the device.
 int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, size_t stage_off) {
-  constexpr int NT = 4;
+  constexpr int NT_MAX = 8;
+  const int NT = ctx->h2d_threads;
   constexpr size_t SMALL = 8u << 20, PIECE = 4u << 20;
   if (bytes < SMALL) {  // not worth four threads
     HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
@@ -1823,7 +1825,7 @@ int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, s
       HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));  // fall back to the runtime's pageable path
       return MSM377_OK;
     }
-    for (int t = 0; t < NT; t++) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
+    for (int t = 0; t < NT_MAX; t++) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
   }
   // Pieces of about 4 MB, their number a multiple of the worker count: every worker copies the same amount (with
   // fixed 8 MB pieces a 48 MB upload took as long as a 64 MB one), and a worker's host copy of piece k+1 overlaps
@@ -1832,8 +1834,8 @@ int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, s
   npieces = (npieces + NT - 1) / NT * NT;
   const size_t piece = ((bytes + npieces - 1) / npieces + 4095) & ~(size_t)4095;
   uint8_t* stage = ctx->h_stage + stage_off;
-  hipError_t errs[NT];
-  std::thread workers[NT];
+  hipError_t errs[NT_MAX];
+  std::thread workers[NT_MAX];
   const int device = ctx->device;
   for (int t = 0; t < NT; t++) {
     errs[t] = hipSuccess;
@@ -2558,6 +2560,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_H2D_THREADS")) ctx->h2d_threads = std::min(std::max(atoi(e), 1), 8);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 8);
   if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 10), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
@@ -2659,7 +2662,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->h_aff_flag) (void)hipHostFree(ctx->h_aff_flag);
   if (ctx->aff_up_done) (void)hipEventDestroy(ctx->aff_up_done);
   if (ctx->sort_done) (void)hipEventDestroy(ctx->sort_done);
-  for (int t = 0; t < 4; t++)
+  for (int t = 0; t < 8; t++)
     if (ctx->copy_stream[t]) (void)hipStreamDestroy(ctx->copy_stream[t]);
   for (int k = 0; k < 2; k++)
     if (ctx->done_ev[k]) (void)hipEventDestroy(ctx->done_ev[k]);
