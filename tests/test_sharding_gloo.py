@@ -58,7 +58,20 @@ def _worker(rank, world, port, case_name, q):
             ctypes.memmove(d_out, data, len(data))
 
         out4 = sh.run_resident(write_records)
-        q.put((rank, out == case["expected"] and out2 == out and out3 == out and out4 == out))
+
+        # with a combine callback (MsmEngine.combine_partials on the GPU box): uniform window counts hand it the address of
+        # the gathered buffer itself, ragged ones the re-packed bytes
+        seen = []
+
+        def combine(parts):
+            seen.append(type(parts).__name__)
+            if isinstance(parts, int):
+                parts = ctypes.string_at(parts, 16 * 3072)
+            return msm.combine_partials(parts)
+
+        out5 = sh.run_resident(write_records, combine)
+        ok_kind = seen == (["int"] if 16 % world == 0 else ["bytes"])
+        q.put((rank, out == case["expected"] and out2 == out and out3 == out and out4 == out and out5 == out and ok_kind))
     finally:
         dist.destroy_process_group()
 

@@ -96,8 +96,11 @@ class ShardedMsm:
                 fn(self.begin, self.count, self.send_dev.data_ptr())
             dist.all_gather_into_tensor(self.recv_dev, self.send_dev, group=self.group)
             self.recv_host.copy_(self.recv_dev)  # synchronising D2H
-            flat = self.recv_host.numpy()
-            parts = b"".join(flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts))
+            if combine is not None and self.num_windows == NUM_WINDOWS and all(c == self.max_count for c in self.counts):
+                parts = self.recv_host.data_ptr()  # every slot is full: the gathered buffer IS the 16 records, combined in place
+            else:
+                flat = self.recv_host.numpy()
+                parts = b"".join(flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts))
             try:
                 return combine(parts) if combine is not None else combine_partials_bytes(parts, self.num_windows)
             except MsmError as e:
