@@ -82,7 +82,8 @@ int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
 /* Fixed-base batches (BASELINE.json config 5): convert and keep a base set in HBM once ... */
 int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
 int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n);
-/* The same with precomputed window multiples (BASELINE.json config 5, "precomputed-point reuse"): additionally keeps
+/* The same with precomputed window multiples (BASELINE.json config 5, "precomputed-point reuse"; the reference lists
+ * precomputation among its own future improvements, /root/reference README.md:558-563): additionally keeps
  * [2^(16 w)] P_i for all 16 windows (16 n affine records: 2.7 GB at n = 2^20, allocated on demand, ~45 ms once).  Every
  * window then gathers points that already carry its weight, so the sixteen bucket sets are simply added together on the
  * GPU: ONE bucket reduction, one partial record and a 16-step host tail per MSM instead of 16 and 256.  Results are
