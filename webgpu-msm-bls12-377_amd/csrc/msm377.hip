@@ -4,22 +4,26 @@
 //
 // Pipeline (each stage names the reference code it replaces; paths relative to
 // /root/reference/src/submission/):
-//   k_convert_bases   wire x||y -> Montgomery records            wgsl/cuzk/convert_point_coords_and_decompose_scalars.template.wgsl:41-99 + barrett.template.wgsl:60-82
-//   k_decompose       scalars -> signed 16-bit digits            same file :100-141; model cuzk/utils.ts:66-109
-//   k_range_count / k_range_scan / k_partition / k_local_sort
+//   k_affine_up / host inversion / k_affine_down (n >= 2^20, resident tables), k_convert_bases (otherwise)
+//                     wire x||y -> Montgomery records            wgsl/cuzk/convert_point_coords_and_decompose_scalars.template.wgsl:41-99 + barrett.template.wgsl:60-82
+//   k_decompose (16-bit windows), k_decompose_narrow (inputs <= 2^15 points: 11-bit windows, submission.ts:97)
+//                     scalars -> signed digits                   same file :100-141; model cuzk/utils.ts:66-109
+//   k_range_count / k_range_scan / k_partition / k_local_sort (k_small_sort on the narrow path)
 //                     per-window counting sort -> CSR            wgsl/cuzk/transpose_serial.wgsl:34-76 (16 serial threads there); model cuzk/transpose.ts:14-62
 //   k_accumulate      bucket sums (the dominant kernel)          wgsl/cuzk/smvp_bls12_377.template.wgsl:72-160
-//   k_tree_step       bucket reduction, log-depth bit planes     wgsl/cuzk/bpr.template.wgsl:69-173; models cuzk/bpr.ts:5-126
+//   k_tree_step / k_tree_step_quad / k_reduce_tail
+//                     bucket reduction, log-depth bit planes     wgsl/cuzk/bpr.template.wgsl:69-173; models cuzk/bpr.ts:5-126
 //   host tail         Horner over windows + one inversion        submission.ts:290-321
-// The kernels are templates over a curve policy: TeDev (default: G1 in twisted Edwards form, te377.hpp -- 8 field
-// products per bucket addition, unified law, exceptional cases detected and rerun), G1Dev (G1 in Weierstrass XYZZ
-// coordinates, g1_xyzz.hpp: the fallback, the GLV front end, the stage read-backs) and EdDev (Edwards-BLS12 over
-// the scalar field, ed_ext.hpp).
+// The kernels are templates over a curve policy: TeDev (default: G1 in twisted Edwards form, te377.hpp -- 7 field
+// products per bucket addition on affine base records (TeAffBase), 8 on projective ones, unified law, exceptional cases
+// detected and rerun), G1Dev (G1 in Weierstrass XYZZ coordinates, g1_xyzz.hpp: the fallback, the GLV front end, the
+// stage read-backs) and EdDev (Edwards-BLS12 over the scalar field, ed_ext.hpp).  Everything behind the sort takes the
+// bucket geometry as a run-time argument L (2^L buckets per window: 15 on the main path, 11 on the narrow one).
 //
-// HBM layout (n points, W window slots, NB = 32768 buckets per window):
-//   bases    TeDev: n x 256 B records (Y-X)[13] (Y+X)[13] (2dT)[13] (2Z)[13] pad[12] u32; G1Dev: n x 128 B
-//            x[13] y[13] pad[6] (29-bit limbs, Montgomery R = 2^406); records are line-aligned, so a gather
-//            touches exactly two (one) 128-byte lines
+// HBM layout (n points, W window slots, NB = 32768 buckets per window on the main path):
+//   bases    TeDev: n x 160 B affine records (y-x)[13] (y+x)[13] (2dxy)[13] pad[1] u32 (TeAffBase) or n x 256 B
+//            projective records (Y-X)[13] (Y+X)[13] (2dT)[13] (2Z)[13] pad[12]; G1Dev: n x 128 B x[13] y[13] pad[6]
+//            (29-bit limbs, Montgomery R = 2^406); a gather touches two (one) 128-byte lines
 //   digits   W x n u16, window-major: biased digit d + 2^15 (the reference's chunks[] as u32)
 //   row_ptr  W x 32770 u32: CSR offsets over keys |d| in 0..32768 (the reference keeps 65537
 //            signed rows; here +t and -t share row t and the sign rides in val_idx bit 31)
@@ -1763,7 +1767,6 @@ struct msm377_ctx {
   bool merge_full_grid = true;  // MSM377_MERGE_FULL_GRID=0: fixed 64-workgroup sweep of the split-row list (A/B knob)
   bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
   uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
-  int acc_occ = 2;  // MSM377_ACC_OCC=3: build of k_accumulate limited to 168 VGPRs (A/B knob)
   hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
   hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
   hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
@@ -2114,12 +2117,6 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       const dim3 grid((unsigned)((max_items + 255) / 256));
       if constexpr (!std::is_same<BP, CV>::value)
         hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
-      else if (ctx->acc_occ == 4)
-        hipLaunchKernelGGL((k_accumulate<CV, 4>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
-      else if (ctx->acc_occ == 3)
-        hipLaunchKernelGGL((k_accumulate<CV, 3>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
                            ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
@@ -2556,7 +2553,6 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (!ctx) return MSM377_ENOMEM;
   ctx->device = device;
   ctx->cap = max_points;
-  if (const char* e = getenv("MSM377_ACC_OCC")) ctx->acc_occ = atoi(e);
   if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
