@@ -403,6 +403,11 @@ struct TeChecked {
     bad |= Fp64::is_zero(r.z);
     return r;
   }
+  TeH::Ext dbl_nt(const TeH::Ext& a) {  // no T: only before another doubling
+    const TeH::Ext r = TeH::dbl_nt(a);
+    bad |= Fp64::is_zero(r.z);
+    return r;
+  }
 };
 // Same Horner as g1h_combine over Edwards partial records.
 inline bool teh_is_identity(const TeH::Ext& p) { return Fp64::is_zero(p.x) && Fp64::is_zero(Fp64::sub(p.y, p.z)); }

@@ -1612,7 +1612,7 @@ __global__ void __launch_bounds__(256, 2) k_generate_bases_ed(uint64_t seed, uin
 // 5 % of a 2^20 MSM -- and it is the one stage nothing else can hide).  Workers sleep on a condition variable
 // between calls; a call publishes up to three jobs and collects them in the order it needs them.
 struct TailPool {
-  static constexpr int WORKERS = 3;
+  static constexpr int WORKERS = 7;
   std::thread th[WORKERS];
   std::mutex mu;
   std::condition_variable cv;
@@ -1776,7 +1776,7 @@ struct msm377_ctx {
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;
-  int tail_threads = 4;               // MSM377_TAIL_THREADS=1: single-threaded host tail
+  int tail_threads = 6;               // MSM377_TAIL_THREADS: threads of the host tail (1..8; 16 windows: 6 blocks of 3 + the stitching)
   // MSM377_TAIL_SPIN_US: how long the tail workers poll for their job after a call has armed them (TailPool).  Off by
   // default: interleaved runs with 0 / 4000 us showed no difference (tail 0.122-0.149 ms either way at 2^14 and 2^20) --
   // the tail is bound by its ~2 600 serial field multiplications, not by the workers' wake-up.
@@ -1957,10 +1957,12 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
   if (nblk >= 32 && ctx->tail_threads > 1) {
     TailPool& pool = ctx->tail_pool;
     pool.start();
-    const uint32_t per = (nblk + 3) / 4;
-    for (int k = 0; k < 3; k++) pool.post(k, [ctx, k, per, nblk] { invert_block_products(ctx, std::min(nblk, (uint32_t)(k + 1) * per), std::min(nblk, (uint32_t)(k + 2) * per)); });
+    const int parts = std::min(ctx->tail_threads, TailPool::WORKERS + 1);
+    const uint32_t per = (nblk + parts - 1) / parts;
+    for (int k = 0; k + 1 < parts; k++)
+      pool.post(k, [ctx, k, per, nblk] { invert_block_products(ctx, std::min(nblk, (uint32_t)(k + 1) * per), std::min(nblk, (uint32_t)(k + 2) * per)); });
     invert_block_products(ctx, 0, std::min(nblk, per));
-    for (int k = 0; k < 3; k++) pool.wait(k);
+    for (int k = 0; k + 1 < parts; k++) pool.wait(k);
   } else {
     invert_block_products(ctx, 0, nblk);
   }
@@ -2310,20 +2312,26 @@ int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) 
   return convert_bases_g1(ctx, d_raw, n, form == TABLE_XYZZ_GLV);
 }
 
-// Host tail of ONE 16-window MSM on four threads: the windows are cut into four blocks of four, every block is a
-// 64-step Horner chain of its own (three of them on the pool), and the caller stitches them together top-down with
-// 64 doublings between blocks -- 64 x (dbl + add) + 192 dbl on the critical path instead of 256 x (dbl + add).
-template <class Pt, class HornerFn, class DblFn, class AddFn>
-Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, DblFn dbl, AddFn add, int num_windows = MSM377_NUM_WINDOWS, int cbits = 16) {
-  const int block = (num_windows + 3) / 4;  // windows per block; the top block (the caller's) may be shorter
+// Host tail of ONE MSM on `blocks` threads (MSM377_TAIL_THREADS, at most 8): the windows are cut into that many blocks,
+// every block is a Horner chain of its own (all but the top one on the pool), and the caller stitches them together
+// top-down with `cbits * block` doublings between blocks -- with 4 blocks of 4 windows 64 x (dbl + add) + 192 dbl on the
+// critical path instead of 256 x (dbl + add), with 8 blocks 32 x (dbl + add) + 224 dbl.  `dbl_nt` is a doubling whose
+// result is only doubled again (the Edwards form saves a product there).
+template <class Pt, class HornerFn, class DblFn, class DblNtFn, class AddFn>
+Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, DblFn dbl, DblNtFn dbl_nt, AddFn add, int num_windows = MSM377_NUM_WINDOWS,
+                  int cbits = 16) {
+  const int blocks = std::min(std::min(ctx->tail_threads, TailPool::WORKERS + 1), num_windows);
+  const int block = (num_windows + blocks - 1) / blocks;  // windows per block; the top block (the caller's) may be shorter
+  const int used = (num_windows + block - 1) / block;     // blocks that hold windows
   TailPool& pool = ctx->tail_pool;
   pool.start();
-  Pt part[3];
-  for (int k = 0; k < 3; k++)  // block k = windows k block .. (k + 1) block - 1
+  Pt part[TailPool::WORKERS];
+  for (int k = 0; k + 1 < used; k++)  // block k = windows k block .. (k + 1) block - 1
     pool.post(k, [&part, k, partials, horner, block] { part[k] = horner(partials + (size_t)k * block * 16 * 48, block); });
-  Pt acc = horner(partials + (size_t)3 * block * 16 * 48, num_windows - 3 * block);
-  for (int k = 2; k >= 0; k--) {
-    for (int i = 0; i < cbits * block; i++) acc = dbl(acc);
+  Pt acc = horner(partials + (size_t)(used - 1) * block * 16 * 48, num_windows - (used - 1) * block);
+  for (int k = used - 2; k >= 0; k--) {
+    for (int i = 0; i + 1 < cbits * block; i++) acc = dbl_nt(acc);
+    acc = dbl(acc);
     pool.wait(k);
     acc = add(acc, part[k]);
   }
@@ -2334,12 +2342,19 @@ Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, Db
 // out_xy untouched) -- the caller reruns on the Weierstrass path, exactly as for the GPU-side flag.
 bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows = MSM377_NUM_WINDOWS, int cbits = 16, int planes = 15) {
   if (ctx->tail_threads <= 1 || num_windows < 8) return teh_combine(partials, num_windows, out_xy, cbits, planes);
-  const int block = (num_windows + 3) / 4;
-  TeChecked chk[4];  // one per block chain (three of them on pool threads), chk[3] also covers the stitching
+  const int blocks = std::min(std::min(ctx->tail_threads, TailPool::WORKERS + 1), num_windows);
+  const int block = (num_windows + blocks - 1) / blocks;
+  TeChecked chk[TailPool::WORKERS + 1];  // one per block chain; the last one also covers the stitching
+  TeChecked& mine = chk[TailPool::WORKERS];
   const TeH::Ext r = tail_horner_mt<TeH::Ext>(
-      ctx, partials, [&chk, partials, block, cbits, planes](const uint32_t* p, int nw) { return teh_horner(p, nw, chk[(p - partials) / ((size_t)block * 16 * 48)], 0, cbits, planes); },
-      [&chk](const TeH::Ext& a) { return chk[3].dbl(a); }, [&chk](const TeH::Ext& a, const TeH::Ext& b) { return chk[3].add(a, b); }, num_windows, cbits);
-  if (chk[0].bad || chk[1].bad || chk[2].bad || chk[3].bad) return true;
+      ctx, partials,
+      [&chk, partials, block, cbits, planes](const uint32_t* p, int nw) {
+        return teh_horner(p, nw, chk[std::min<size_t>((p - partials) / ((size_t)block * 16 * 48), TailPool::WORKERS)], 0, cbits, planes);
+      },
+      [&mine](const TeH::Ext& a) { return mine.dbl(a); }, [&mine](const TeH::Ext& a) { return mine.dbl_nt(a); },
+      [&mine](const TeH::Ext& a, const TeH::Ext& b) { return mine.add(a, b); }, num_windows, cbits);
+  for (const TeChecked& c : chk)
+    if (c.bad) return true;
   teh_to_wire(r, out_xy);
   return false;
 }
@@ -2348,7 +2363,7 @@ void xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
   if (ctx->tail_threads <= 1) return g1h_combine(partials, MSM377_NUM_WINDOWS, out_xy);
   const G1H::XYZZ r = tail_horner_mt<G1H::XYZZ>(
       ctx, partials, [](const uint32_t* p, int nw) { return g1h_horner(p, nw); }, [](const G1H::XYZZ& a) { return G1H::dbl(a); },
-      [](const G1H::XYZZ& a, const G1H::XYZZ& b) { return G1H::add(a, b); });
+      [](const G1H::XYZZ& a) { return G1H::dbl(a); }, [](const G1H::XYZZ& a, const G1H::XYZZ& b) { return G1H::add(a, b); });
   g1h_to_wire(r, out_xy);
 }
 
