@@ -52,6 +52,7 @@ def main():
     ms = [[] for _ in engines]
     acc = [[] for _ in engines]
     red = [[] for _ in engines]
+    tail = [[] for _ in engines]
     for _ in range(args.reps):
         for i, eng in enumerate(engines):
             t0 = time.perf_counter()
@@ -60,8 +61,9 @@ def main():
             ms[i].append((time.perf_counter() - t0) * 1e3 / args.iters)
             acc[i].append(eng.stage_ms()["accumulate_kernel"])
             red[i].append(eng.stage_ms()["reduce"])
-    for cfg, m, a, r in zip(args.configs, ms, acc, red):
-        print("%-48s median %.4f  min %.4f  acc_kernel %.4f  reduce %.4f" % (cfg, statistics.median(m), min(m), statistics.median(a), statistics.median(r)), flush=True)
+            tail[i].append(eng.stage_ms()["tail"])
+    for cfg, m, a, r, t in zip(args.configs, ms, acc, red, tail):
+        print("%-48s median %.4f  min %.4f  acc_kernel %.4f  reduce %.4f  tail %.4f" % (cfg, statistics.median(m), min(m), statistics.median(a), statistics.median(r), statistics.median(t)), flush=True)
 
 
 if __name__ == "__main__":

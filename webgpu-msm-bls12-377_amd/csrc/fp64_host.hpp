@@ -329,9 +329,10 @@ inline void g1h_to_wire(const G1H::XYZZ& p, uint8_t out[96]) {
 // double-and-add over bit positions b = 16 w + l (16 windows on the plain path, 8 behind the GLV
 // front end).  partials layout: [window][point][48 words], point 0 =
 // Sum_w, point 1 + l = Plane_{w,l}.
-inline G1H::XYZZ g1h_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
+// Bit positions [lo, hi) of the chain only (position b = 16 w + l): sum_b 2^(b - lo) record_b.
+inline G1H::XYZZ g1h_horner_bits(const uint32_t* partials, int lo, int hi, uint32_t skip_windows = 0) {
   G1H::XYZZ acc = G1H::identity();
-  for (int b = 16 * num_windows - 1; b >= 0; b--) {
+  for (int b = hi - 1; b >= lo; b--) {
     acc = G1H::dbl(acc);
     const int w = b >> 4, l = b & 15;
     if ((skip_windows >> w) & 1u) continue;
@@ -340,6 +341,9 @@ inline G1H::XYZZ g1h_horner(const uint32_t* partials, int num_windows, uint32_t 
     if (l == 0) acc = G1H::add(acc, g1h_from_record_words(base));
   }
   return acc;
+}
+inline G1H::XYZZ g1h_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
+  return g1h_horner_bits(partials, 0, 16 * num_windows, skip_windows);
 }
 inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) { g1h_to_wire(g1h_horner(partials, num_windows), out); }
 
@@ -391,7 +395,8 @@ inline void teh_to_wire(const TeH::Ext& p, uint8_t out[96]) {
 // lead back to Z != 0 with a wrong value.  The GPU kernels check every addition; so does the tail: every add / dbl
 // below reports Z3 = 0 through the sticky flag and the caller reruns on the Weierstrass path.  (Inside the
 // prime-order subgroup this never fires.)
-struct TeChecked {
+// (One per thread, written on every operation: a cache line pair of its own, or the tail threads fight over the line.)
+struct alignas(128) TeChecked {
   bool bad = false;
   TeH::Ext add(const TeH::Ext& a, const TeH::Ext& b) {
     const TeH::Ext r = TeH::add(a, b);
@@ -413,9 +418,10 @@ struct TeChecked {
 inline bool teh_is_identity(const TeH::Ext& p) { return Fp64::is_zero(p.x) && Fp64::is_zero(Fp64::sub(p.y, p.z)); }
 // cbits: distance of two windows in bits (16 on the main path, 11 on the narrow-window path for small inputs);
 // planes: bit planes per window record = log2 of its buckets (15 / 11), all inside the same 16-point record.
-inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
+// Bit positions [lo, hi) of the chain only (position b = cbits w + l): sum_b 2^(b - lo) record_b.
+inline TeH::Ext teh_horner_bits(const uint32_t* partials, int lo, int hi, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
   TeH::Ext acc = TeH::identity();
-  for (int b = cbits * num_windows - 1; b >= 0; b--) {
+  for (int b = hi - 1; b >= lo; b--) {
     acc = chk.dbl(acc);
     const int w = b / cbits, l = b % cbits;
     if ((skip_windows >> w) & 1u) continue;
@@ -431,6 +437,9 @@ inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked&
     }
   }
   return acc;
+}
+inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
+  return teh_horner_bits(partials, 0, cbits * num_windows, chk, skip_windows, cbits, planes);
 }
 // false: done; true: an exceptional case of the law (out untouched).
 inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96], int cbits = 16, int planes = 15) {
@@ -537,17 +546,18 @@ inline void edh_to_wire(const EdH::Ext& p, uint8_t out[64]) {
   Fq64::to_wire(Fq64::mul(p.x, zi), out);
   Fq64::to_wire(Fq64::mul(p.y, zi), out + 32);
 }
-// Same Horner as g1h_combine; partials layout [window][point][32 words].
-inline void edh_combine(const uint32_t* partials, uint8_t out[64]) {
+// Same Horner as g1h_horner_bits; partials layout [window][point][32 words].  Bit positions [lo, hi) of the chain.
+inline EdH::Ext edh_horner_bits(const uint32_t* partials, int lo, int hi) {
   EdH::Ext acc = EdH::identity();
-  for (int b = 255; b >= 0; b--) {
+  for (int b = hi - 1; b >= lo; b--) {
     acc = EdH::dbl(acc);
     const int w = b >> 4, l = b & 15;
     const uint32_t* base = partials + (size_t)w * 16 * 32;
     if (l < 15) acc = EdH::add(acc, edh_from_record_words(base + (size_t)(1 + l) * 32));
     if (l == 0) acc = EdH::add(acc, edh_from_record_words(base));
   }
-  edh_to_wire(acc, out);
+  return acc;
 }
+inline void edh_combine(const uint32_t* partials, uint8_t out[64]) { edh_to_wire(edh_horner_bits(partials, 0, 256), out); }
 
 }  // namespace msm377

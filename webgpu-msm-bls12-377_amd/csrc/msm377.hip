@@ -1619,11 +1619,13 @@ struct TailPool {
   std::function<void()> job[WORKERS];
   std::atomic<uint64_t> posted[WORKERS];   // generation of the last job handed to worker k (written under mu)
   std::atomic<uint64_t> done[WORKERS];     // generation worker k has finished
-  // Workers asleep on the condition variable take 20-60 us to come back -- as long as their whole job (a 64-step Horner
-  // chain is ~45 us) -- so a call that will need them ARMS the pool when it starts (prewake): the workers wake up
-  // while the GPU computes and poll for their job until the deadline, then go back to sleep.  Costs three spinning
-  // cores for at most `spin_us` per call (MSM377_TAIL_SPIN_US, 0 = never spin).
+  // Workers asleep on the condition variable take 20-60 us to come back -- as long as their whole job (a piece of the
+  // Horner chain is ~55 us) -- so a call that will need them ARMS the pool (prewake) once its accumulation kernel has
+  // finished: the first `count` workers wake up while the GPU reduces the buckets (0.1-0.3 ms) and poll for their
+  // job until the deadline, then go back to sleep.  Costs that many spinning cores for the length of the bucket
+  // reduction, at most `spin_us` per call (MSM377_TAIL_SPIN_US, 0 = never spin).
   std::atomic<int64_t> armed_until_ns{0};
+  std::atomic<int> armed_count{0};
   bool stop = false, started = false;
   TailPool() {
     for (auto& d : done) d.store(0);
@@ -1640,7 +1642,10 @@ struct TailPool {
           std::function<void()> f;
           {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || posted[k].load(std::memory_order_relaxed) != seen || now_ns() < armed_until_ns.load(std::memory_order_relaxed); });
+            cv.wait(lk, [&] {
+              return stop || posted[k].load(std::memory_order_relaxed) != seen ||
+                     (k < armed_count.load(std::memory_order_relaxed) && now_ns() < armed_until_ns.load(std::memory_order_relaxed));
+            });
             if (stop) return;
             if (posted[k].load(std::memory_order_relaxed) == seen) {  // armed: poll without the lock until the job or the deadline comes
               lk.unlock();
@@ -1657,10 +1662,14 @@ struct TailPool {
         }
       });
   }
-  void prewake(int64_t spin_us) {
-    if (spin_us <= 0) return;
+  void prewake(int64_t spin_us, int count = WORKERS) {
+    if (spin_us <= 0 || count <= 0) return;
     start();
-    armed_until_ns.store(now_ns() + spin_us * 1000, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(mu);  // with the lock: a worker between its predicate and its sleep must not miss this
+      armed_count.store(std::min(count, (int)WORKERS), std::memory_order_relaxed);
+      armed_until_ns.store(now_ns() + spin_us * 1000, std::memory_order_relaxed);
+    }
     cv.notify_all();
   }
   void disarm() { armed_until_ns.store(0, std::memory_order_relaxed); }
@@ -1776,11 +1785,12 @@ struct msm377_ctx {
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;
-  int tail_threads = 6;               // MSM377_TAIL_THREADS: threads of the host tail (1..8; 16 windows: 6 blocks of 3 + the stitching)
-  // MSM377_TAIL_SPIN_US: how long the tail workers poll for their job after a call has armed them (TailPool).  Off by
-  // default: interleaved runs with 0 / 4000 us showed no difference (tail 0.122-0.149 ms either way at 2^14 and 2^20) --
-  // the tail is bound by its ~2 600 serial field multiplications, not by the workers' wake-up.
-  int64_t tail_spin_us = 0;
+  int tail_threads = 6;               // MSM377_TAIL_THREADS: threads of the host tail (1..8, tail_horner_mt)
+  // MSM377_TAIL_SPIN_US: how long at most the tail workers poll for their job after a call has armed them (TailPool;
+  // 0 = they sleep until the job is posted).  Tail stage at 2^20, interleaved (tools/ab_knobs.py): one thread 0.140 ms,
+  // six sleeping workers 0.124, six polling ones 0.089.  (Round 2 first measured no difference: the per-thread
+  // exceptional-case flags shared a cache line then and the threads fought over it -- TeChecked is padded now.)
+  int64_t tail_spin_us = 1000;
   int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
   uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
@@ -2312,28 +2322,59 @@ int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) 
   return convert_bases_g1(ctx, d_raw, n, form == TABLE_XYZZ_GLV);
 }
 
-// Host tail of ONE MSM on `blocks` threads (MSM377_TAIL_THREADS, at most 8): the windows are cut into that many blocks,
-// every block is a Horner chain of its own (all but the top one on the pool), and the caller stitches them together
-// top-down with `cbits * block` doublings between blocks -- with 4 blocks of 4 windows 64 x (dbl + add) + 192 dbl on the
-// critical path instead of 256 x (dbl + add), with 8 blocks 32 x (dbl + add) + 224 dbl.  `dbl_nt` is a doubling whose
-// result is only doubled again (the Edwards form saves a product there).
-template <class Pt, class HornerFn, class DblFn, class DblNtFn, class AddFn>
-Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, DblFn dbl, DblNtFn dbl_nt, AddFn add, int num_windows = MSM377_NUM_WINDOWS,
-                  int cbits = 16) {
-  const int blocks = std::min(std::min(ctx->tail_threads, TailPool::WORKERS + 1), num_windows);
-  const int block = (num_windows + blocks - 1) / blocks;  // windows per block; the top block (the caller's) may be shorter
-  const int used = (num_windows + block - 1) / block;     // blocks that hold windows
+// Host tail of ONE MSM on up to 8 threads (MSM377_TAIL_THREADS).  The Horner chain over the `positions` = windows x
+// cbits bit positions is cut into one piece per thread; the thread that owns positions [lo, hi) runs its own chain
+// (hi - lo steps of doubling + addition, ~17 field products each) and then doubles its result `lo` times (7 products
+// each: `dbl_nt`, a doubling whose result is only doubled again, skips T in the Edwards form), and the caller adds
+// the pieces up.  The cuts balance (hi - lo) x 17 + lo x 7 over the threads, so the pieces shrink towards the top:
+// 256 positions on 6 threads are 110 / 65 / 38 / 22 / 13 / 8 positions and ~1 900 products on the critical path,
+// against 2 496 for six equal blocks stitched by the caller and ~4 350 for one thread.
+constexpr double TAIL_STEP_COST = 17.0, TAIL_DBL_COST = 7.0;
+inline int tail_split(int positions, int chains, int* bounds) {  // bounds[0 .. used]; returns used <= chains
+  double lo = 0.0, hi = positions * TAIL_STEP_COST;
+  auto reach = [&](double t) {
+    double o = 0.0;
+    for (int k = 0; k < chains; k++) o += std::max(0.0, (t - TAIL_DBL_COST * o) / TAIL_STEP_COST);
+    return o;
+  };
+  for (int it = 0; it < 48; it++) {
+    const double t = 0.5 * (lo + hi);
+    (reach(t) >= positions ? hi : lo) = t;
+  }
+  int used = 0;
+  double o = 0.0;
+  bounds[0] = 0;
+  for (int k = 0; k < chains && bounds[used] < positions; k++) {
+    o += std::max(0.0, (hi - TAIL_DBL_COST * o) / TAIL_STEP_COST);
+    const int b = k + 1 == chains ? positions : std::min(positions, (int)(o + 0.5));
+    if (b > bounds[used]) bounds[++used] = b;
+  }
+  bounds[used] = positions;
+  return used;
+}
+
+// range(lo, hi, chain) -> sum of the positions' records x 2^(position - lo); dbl / dbl_nt / add take the chain index
+// too (the Edwards form keeps one exceptional-case record per chain).
+template <class Pt, class RangeFn, class DblFn, class DblNtFn, class AddFn>
+Pt tail_horner_mt(msm377_ctx* ctx, RangeFn range, DblFn dbl, DblNtFn dbl_nt, AddFn add, int positions) {
+  constexpr int MAXC = TailPool::WORKERS + 1;
+  int bounds[MAXC + 1];
+  const int used = tail_split(positions, std::max(1, std::min(ctx->tail_threads, MAXC)), bounds);
   TailPool& pool = ctx->tail_pool;
-  pool.start();
-  Pt part[TailPool::WORKERS];
-  for (int k = 0; k + 1 < used; k++)  // block k = windows k block .. (k + 1) block - 1
-    pool.post(k, [&part, k, partials, horner, block] { part[k] = horner(partials + (size_t)k * block * 16 * 48, block); });
-  Pt acc = horner(partials + (size_t)(used - 1) * block * 16 * 48, num_windows - (used - 1) * block);
+  if (used > 1) pool.start();
+  Pt part[MAXC];
+  auto chain = [&part, &bounds, range, dbl, dbl_nt](int k) {
+    Pt acc = range(bounds[k], bounds[k + 1], k);
+    for (int i = 0; i + 1 < bounds[k]; i++) acc = dbl_nt(acc, k);
+    if (bounds[k] > 0) acc = dbl(acc, k);
+    part[k] = acc;
+  };
+  for (int k = 0; k + 1 < used; k++) pool.post(k, [&chain, k] { chain(k); });
+  chain(used - 1);  // the top piece: the fewest positions, the most doublings
+  Pt acc = part[used - 1];
   for (int k = used - 2; k >= 0; k--) {
-    for (int i = 0; i + 1 < cbits * block; i++) acc = dbl_nt(acc);
-    acc = dbl(acc);
     pool.wait(k);
-    acc = add(acc, part[k]);
+    acc = add(acc, part[k], used - 1);
   }
   return acc;
 }
@@ -2342,17 +2383,11 @@ Pt tail_horner_mt(msm377_ctx* ctx, const uint32_t* partials, HornerFn horner, Db
 // out_xy untouched) -- the caller reruns on the Weierstrass path, exactly as for the GPU-side flag.
 bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows = MSM377_NUM_WINDOWS, int cbits = 16, int planes = 15) {
   if (ctx->tail_threads <= 1 || num_windows < 8) return teh_combine(partials, num_windows, out_xy, cbits, planes);
-  const int blocks = std::min(std::min(ctx->tail_threads, TailPool::WORKERS + 1), num_windows);
-  const int block = (num_windows + blocks - 1) / blocks;
-  TeChecked chk[TailPool::WORKERS + 1];  // one per block chain; the last one also covers the stitching
-  TeChecked& mine = chk[TailPool::WORKERS];
+  TeChecked chk[TailPool::WORKERS + 1];  // one per chain
   const TeH::Ext r = tail_horner_mt<TeH::Ext>(
-      ctx, partials,
-      [&chk, partials, block, cbits, planes](const uint32_t* p, int nw) {
-        return teh_horner(p, nw, chk[std::min<size_t>((p - partials) / ((size_t)block * 16 * 48), TailPool::WORKERS)], 0, cbits, planes);
-      },
-      [&mine](const TeH::Ext& a) { return mine.dbl(a); }, [&mine](const TeH::Ext& a) { return mine.dbl_nt(a); },
-      [&mine](const TeH::Ext& a, const TeH::Ext& b) { return mine.add(a, b); }, num_windows, cbits);
+      ctx, [&chk, partials, cbits, planes](int lo, int hi, int k) { return teh_horner_bits(partials, lo, hi, chk[k], 0, cbits, planes); },
+      [&chk](const TeH::Ext& a, int k) { return chk[k].dbl(a); }, [&chk](const TeH::Ext& a, int k) { return chk[k].dbl_nt(a); },
+      [&chk](const TeH::Ext& a, const TeH::Ext& b, int k) { return chk[k].add(a, b); }, cbits * num_windows);
   for (const TeChecked& c : chk)
     if (c.bad) return true;
   teh_to_wire(r, out_xy);
@@ -2362,9 +2397,19 @@ bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int 
 void xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
   if (ctx->tail_threads <= 1) return g1h_combine(partials, MSM377_NUM_WINDOWS, out_xy);
   const G1H::XYZZ r = tail_horner_mt<G1H::XYZZ>(
-      ctx, partials, [](const uint32_t* p, int nw) { return g1h_horner(p, nw); }, [](const G1H::XYZZ& a) { return G1H::dbl(a); },
-      [](const G1H::XYZZ& a) { return G1H::dbl(a); }, [](const G1H::XYZZ& a, const G1H::XYZZ& b) { return G1H::add(a, b); });
+      ctx, [partials](int lo, int hi, int) { return g1h_horner_bits(partials, lo, hi); }, [](const G1H::XYZZ& a, int) { return G1H::dbl(a); },
+      [](const G1H::XYZZ& a, int) { return G1H::dbl(a); }, [](const G1H::XYZZ& a, const G1H::XYZZ& b, int) { return G1H::add(a, b); },
+      16 * MSM377_NUM_WINDOWS);
   g1h_to_wire(r, out_xy);
+}
+
+void ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64]) {  // Edwards-BLS12: a complete law, nothing to check
+  if (ctx->tail_threads <= 1) return edh_combine(partials, out_xy);
+  const EdH::Ext r = tail_horner_mt<EdH::Ext>(
+      ctx, [partials](int lo, int hi, int) { return edh_horner_bits(partials, lo, hi); }, [](const EdH::Ext& a, int) { return EdH::dbl(a); },
+      [](const EdH::Ext& a, int) { return EdH::dbl_nt(a); }, [](const EdH::Ext& a, const EdH::Ext& b, int) { return EdH::add(a, b); },
+      16 * MSM377_NUM_WINDOWS);
+  edh_to_wire(r, out_xy);
 }
 
 void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
@@ -2376,11 +2421,15 @@ void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
 // hit an exceptional case (the caller reconverts and reruns).  TABLE_XYZZ_GLV: the GLV front end; a scalar outside
 // its range (bit 1 of the error word) reruns on the plain 16-window path, whose records 0..n-1 of the table are
 // the plain points either way.
-// Arms the tail workers for the length of one call (TailPool::prewake); disarmed when the tail is done.
+// Arms the tail workers of one call once its accumulation kernel is through (TailPool::prewake: they poll for their
+// jobs while the GPU reduces the buckets); disarmed when the tail is done.
 struct TailArm {
   msm377_ctx* c;
-  explicit TailArm(msm377_ctx* ctx) : c(ctx) {
-    if (c->tail_threads > 1) c->tail_pool.prewake(c->tail_spin_us);
+  explicit TailArm(msm377_ctx* ctx) : c(ctx) {}
+  void after_accumulation() {
+    if (c->tail_threads <= 1 || c->tail_spin_us <= 0) return;
+    if (hipEventSynchronize(c->acc_done) != hipSuccess) return;  // the caller's own wait reports the error
+    c->tail_pool.prewake(c->tail_spin_us, std::min(c->tail_threads, TailPool::WORKERS + 1) - 1);
   }
   ~TailArm() { c->tail_pool.disarm(); }
 };
@@ -2411,6 +2460,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, windows, 0, false, ph)
                                 : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, windows, 0, false, ph);
       if (rc) return rc;
+      arm.after_accumulation();
       HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
       if (narrow && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar >= 2^253: the 16-bit path takes it
         narrow = false;
@@ -2803,11 +2853,15 @@ int msm377_ed_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   ctx->bases_n = 0;
   rc = convert_bases<EdDev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
-  rc = run_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS);
+  TailArm arm(ctx);
+  rc = enqueue_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
+  if (rc) return rc;
+  arm.after_accumulation();
+  rc = finish_windows(ctx, 0);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
-  edh_combine(ctx->h_partials, out_xy);
-  ctx->stage_ms[MSM377_STAGE_TAIL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ed_tail(ctx, ctx->h_partials, out_xy);
+  time_tail(ctx, t0);
   return MSM377_OK;
 }
 
@@ -2827,7 +2881,7 @@ int msm377_ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars
     rc = finish_windows(ctx, 0);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    edh_combine(ctx->h_partials, out_xy);
+    ed_tail(ctx, ctx->h_partials, out_xy);
     time_tail(ctx, t0);
     return MSM377_OK;
   }
@@ -3032,7 +3086,7 @@ static int window_partials(msm377_ctx* ctx, const void* d_points, const void* d_
   }
   const size_t bytes = (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->tail_threads > 1) ctx->tail_pool.prewake(ctx->tail_spin_us);  // the combine of the gathered records follows (msm377_g1_combine_partials_ctx disarms)
+  if (ctx->tail_threads > 1) ctx->tail_pool.prewake(ctx->tail_spin_us, std::min(ctx->tail_threads, TailPool::WORKERS + 1) - 1);  // the combine of the gathered records follows (msm377_g1_combine_partials_ctx disarms)
   if (n == 0) {  // identity partials: ZZ = 0 everywhere
     if (host_out) memset(host_out, 0, bytes);
     if (dev_out) HIP_TRY(ctx, hipMemset(dev_out, 0, bytes));
