@@ -217,7 +217,10 @@ int msm377_ctx_get_fallback_info(const msm377_ctx* ctx, uint64_t* count, uint32_
 #define MSM377_STAGE_ACC_KERNEL 6  /* the k_accumulate launch alone (inside STAGE_ACCUMULATE, which also
                                       covers the work-list kernels and the split-row merge) */
 #define MSM377_NUM_STAGES 7
-/* Enable HIP-event timing of every stage on the context's stream (off by default). */
+/* HIP-event timing on the context's streams (off by default).  enabled = 1: every stage; 2: the accumulation
+ * kernel alone (MSM377_STAGE_ACC_KERNEL; the other entries read 0).  Every event pair costs a few microseconds of
+ * GPU idle time between the launches it separates -- ~50 us per MSM with all stages on -- so a timed loop that only
+ * needs the kernel's duration uses 2. */
 int msm377_ctx_set_timing(msm377_ctx* ctx, int enabled);
 /* Durations in milliseconds of the last call's stages (MSM377_NUM_STAGES entries; the TAIL
  * entry is host wall time). */

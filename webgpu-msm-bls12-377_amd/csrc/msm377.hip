@@ -251,6 +251,7 @@ struct TeDev {
   static __device__ __forceinline__ Fp::El to64() { return Fp::from_const(G1Consts::TO64); }
   using Base = Te377::PBase;
   using Pt = Te377::Ext;
+  using Pt_K = G1Consts;  // the curve constants of the lazy law (k_accumulate_quad)
   static __device__ __forceinline__ bool convert(const uint32_t* raw, uint32_t* rec) {
     const Base b = Te377::from_wire(raw, raw + 12, false);
 #pragma unroll
@@ -1484,6 +1485,96 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __res
   if (bad) atomicOr(err, ERR_TE_TREE);
 }
 
+// A mixed addition acc + (+-)base on a lane quad: every lane holds the whole accumulator and ONE coordinate of the
+// base record -- lane 0 the factor of Y1 - X1, lane 1 that of Y1 + X1 (the two swap for a negated point, which the
+// caller does by loading the other one), lane 2 (+-) 2d T2, lane 3 2 Z2 -- and computes one product of each of the two
+// rounds of te377.hpp madd: 2 products deep instead of 8.
+template <class F, class K>
+__device__ __forceinline__ typename TeLazy<F, K>::Ext te_madd_quad(const typename TeLazy<F, K>::Ext& a, const typename F::El& mine, uint32_t q) {
+  using El = typename F::El;
+  const El m1 = F::mul_lz(sel4(q, F::add_kp_sub(a.y, K::KP2, a.x), F::add_lz(a.y, a.x), a.t, a.z), mine);
+  const El pa = quad_bcast<0>(m1), pb = quad_bcast<1>(m1), c = quad_bcast<2>(m1), d = quad_bcast<3>(m1);
+  const El e = F::norm(F::add_kp_sub(pb, K::KP2, pa)), f = F::norm(F::add_kp_sub(d, K::KP2, c));
+  const El g = F::norm(F::add_lz(d, c)), h = F::add_lz(pb, pa);
+  const El m3 = F::mul_lz(sel4(q, e, h, h, f), sel4(q, f, g, e, g));
+  typename TeLazy<F, K>::Ext o;
+  o.x = quad_bcast<0>(m3);
+  o.y = quad_bcast<1>(m3);
+  o.t = quad_bcast<2>(m3);
+  o.z = quad_bcast<3>(m3);
+  return o;
+}
+
+// k_accumulate with a lane quad per work item, for inputs so small that the launch is one chain's latency (the
+// narrow-window path: a few thousand short chains, a thread-level addition is ~8 us, a quad-level one ~3).  Same work
+// list, same buckets and overflow records; projective base records (TeDev) only.
+template <class CV>
+__global__ void __launch_bounds__(256, 2) k_accumulate_quad(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
+                                                          const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
+                                                          const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
+                                                          const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG,
+                                                          int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into, uint32_t L) {
+  using El = typename CV::F::El;
+  using K = typename CV::Pt_K;
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t v = gid >> 2, q = threadIdx.x & 3;
+  if (gid == 0 && *conv_err) atomicOr(err, *conv_err);
+  if (v >= *work_total) return;  // whole quads leave together
+  const WorkItem it = work[v];
+  const uint32_t ws = it.row >> L, t = it.row & ((1u << L) - 1);
+  const uint32_t* rp = row_ptr + (size_t)ws * ((1u << L) + 2);
+  const uint32_t* vi = val_idx + (size_t)ws * n;
+  const uint32_t row_beg = rp[t + 1], row_end = rp[t + 2];
+  const uint32_t seglen = row_split(row_end - row_beg, SEG).seglen;
+  uint32_t k = row_beg + it.seg * seglen;
+  const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
+  const bool continues = into && it.seg == 0;  // see k_accumulate
+  typename CV::Pt acc = continues ? load_bucket<CV>(buckets, L, ws, t) : CV::identity();
+  bool bad = false;
+  // the coordinate of entry e's record this lane multiplies by (lane 2: negated below for a negative digit)
+  auto load_mine = [&](uint32_t e) {
+    const bool neg = (e >> 31) != 0;
+    const uint32_t comp = q < 2 ? (q ^ (neg ? 1u : 0u)) : q;
+    const uint32_t* src = bases + (size_t)(e & 0x7fffffffu) * CV::REC_WORDS + comp * CV::NL;
+    El r;
+#pragma unroll
+    for (int j = 0; j < (int)CV::NL; j++) r.l[j] = src[j];
+    return r;
+  };
+  if (k < end && !continues) {  // a chain that starts from the identity: its first entry is a copy (one product), on every lane
+    const uint32_t e = vi[k];
+    acc = CV::first(CV::load_base(bases, e & 0x7fffffffu), (e >> 31) != 0);
+    bad |= CV::is_bad(acc);
+    k++;
+  }
+  if (k < end) {
+    // entry k's coordinate and the index of entry k + 1 are in flight while entry k - 1 is added (as in k_accumulate)
+    uint32_t e_cur = vi[k];
+    uint32_t e_nxt = (k + 1 < end) ? vi[k + 1] : 0u;
+    El cur = load_mine(e_cur);
+    for (;;) {
+      k++;
+      const bool more = k < end;
+      El nxt = cur;
+      uint32_t e_nn = 0u;
+      if (more) {
+        nxt = load_mine(e_nxt);
+        if (k + 1 < end) e_nn = vi[k + 1];
+      }
+      const El mine = (q == 2 && (e_cur >> 31)) ? CV::F::kp_sub(K::KP2, cur) : cur;
+      acc = te_madd_quad<typename CV::F, K>(acc, mine, q);
+      bad |= CV::is_bad(acc);
+      if (!more) break;
+      cur = nxt;
+      e_cur = e_nxt;
+      e_nxt = e_nn;
+    }
+  }
+  if (bad) atomicOr(err, ERR_TE_EXCEPTIONAL);
+  uint32_t* dst = it.seg == 0 ? bucket_ptr<CV>(buckets, L, ws, t) : ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * CV::BKT_WORDS;
+  store_coord<CV>(dst + q * CV::COORD_WORDS, coord4(q, acc).l);  // each lane stores one coordinate
+}
+
 // Quad per split row: bucket += its overflow partials.
 template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
@@ -1613,88 +1704,89 @@ __global__ void __launch_bounds__(256, 2) k_generate_bases_ed(uint64_t seed, uin
 // between calls; a call publishes up to three jobs and collects them in the order it needs them.
 struct TailPool {
   static constexpr int WORKERS = 7;
-  std::thread th[WORKERS];
-  std::mutex mu;
-  std::condition_variable cv;
-  std::function<void()> job[WORKERS];
-  std::atomic<uint64_t> posted[WORKERS];   // generation of the last job handed to worker k (written under mu)
-  std::atomic<uint64_t> done[WORKERS];     // generation worker k has finished
-  // Workers asleep on the condition variable take 20-60 us to come back -- as long as their whole job (a piece of the
+  // Workers asleep on their condition variable take 20-60 us to come back -- as long as their whole job (a piece of the
   // Horner chain is ~55 us) -- so a call that will need them ARMS the pool (prewake) once its accumulation kernel has
   // finished: the first `count` workers wake up while the GPU reduces the buckets (0.1-0.3 ms) and poll for their
   // job until the deadline, then go back to sleep.  Costs that many spinning cores for the length of the bucket
   // reduction, at most `spin_us` per call (MSM377_TAIL_SPIN_US, 0 = never spin).
+  // Every worker has its own slot (job, generation counters, mutex, condition variable) on its own cache lines: posting
+  // a job to a polling worker is two stores, no lock and no system call; only a sleeping worker is notified.
+  struct alignas(128) Slot {
+    std::function<void()> job;
+    std::atomic<uint64_t> posted{0};  // generation of the last job handed to this worker
+    std::atomic<uint64_t> done{0};    // generation it has finished
+    std::atomic<bool> asleep{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread th;
+  };
+  Slot slot[WORKERS];
   std::atomic<int64_t> armed_until_ns{0};
   std::atomic<int> armed_count{0};
-  bool stop = false, started = false;
-  TailPool() {
-    for (auto& d : done) d.store(0);
-    for (auto& d : posted) d.store(0);
-  }
+  std::atomic<bool> stop{false};
+  bool started = false;
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  bool armed(int k) const { return k < armed_count.load(std::memory_order_relaxed) && now_ns() < armed_until_ns.load(std::memory_order_relaxed); }
   void start() {
     if (started) return;
     started = true;
     for (int k = 0; k < WORKERS; k++)
-      th[k] = std::thread([this, k] {
+      slot[k].th = std::thread([this, k] {
+        Slot& me = slot[k];
         uint64_t seen = 0;
         for (;;) {
-          std::function<void()> f;
-          {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] {
-              return stop || posted[k].load(std::memory_order_relaxed) != seen ||
-                     (k < armed_count.load(std::memory_order_relaxed) && now_ns() < armed_until_ns.load(std::memory_order_relaxed));
-            });
-            if (stop) return;
-            if (posted[k].load(std::memory_order_relaxed) == seen) {  // armed: poll without the lock until the job or the deadline comes
-              lk.unlock();
-              while (posted[k].load(std::memory_order_acquire) == seen && now_ns() < armed_until_ns.load(std::memory_order_relaxed)) __builtin_ia32_pause();
-              lk.lock();
-              if (stop) return;
-              if (posted[k].load(std::memory_order_relaxed) == seen) continue;  // deadline passed: back to sleep
+          while (me.posted.load() == seen) {  // (sequentially consistent against post(): one of the two sides sees the other)
+            if (stop.load()) return;
+            if (armed(k)) {
+              __builtin_ia32_pause();
+              continue;
             }
-            seen = posted[k].load(std::memory_order_relaxed);
-            f = job[k];
+            std::unique_lock<std::mutex> lk(me.mu);
+            me.asleep.store(true);
+            me.cv.wait(lk, [&] { return stop.load() || me.posted.load() != seen || armed(k); });
+            me.asleep.store(false);
           }
-          f();
-          done[k].store(seen, std::memory_order_release);
+          seen = me.posted.load();
+          me.job();
+          me.done.store(seen, std::memory_order_release);
         }
       });
+  }
+  void wake(Slot& sl) {
+    if (!sl.asleep.load()) return;
+    std::lock_guard<std::mutex> lk(sl.mu);  // with the lock: a worker between its predicate and its sleep must not miss this
+    sl.cv.notify_one();
   }
   void prewake(int64_t spin_us, int count = WORKERS) {
     if (spin_us <= 0 || count <= 0) return;
     start();
-    {
-      std::lock_guard<std::mutex> lk(mu);  // with the lock: a worker between its predicate and its sleep must not miss this
-      armed_count.store(std::min(count, (int)WORKERS), std::memory_order_relaxed);
-      armed_until_ns.store(now_ns() + spin_us * 1000, std::memory_order_relaxed);
-    }
-    cv.notify_all();
+    armed_count.store(std::min(count, (int)WORKERS));
+    armed_until_ns.store(now_ns() + spin_us * 1000);
+    for (int k = 0; k < std::min(count, (int)WORKERS); k++) wake(slot[k]);
   }
   void disarm() { armed_until_ns.store(0, std::memory_order_relaxed); }
+  // The previous job of worker k must have been waited for (wait(k)): the slot's job is not read any more.
   void post(int k, std::function<void()> f) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      job[k] = std::move(f);
-      posted[k].fetch_add(1, std::memory_order_release);
-    }
-    cv.notify_all();
+    Slot& sl = slot[k];
+    sl.job = std::move(f);
+    sl.posted.fetch_add(1);
+    wake(sl);
   }
   void wait(int k) {  // short: the job is a few tens of microseconds
-    const uint64_t want = posted[k].load(std::memory_order_acquire);
-    while (done[k].load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+    const uint64_t want = slot[k].posted.load(std::memory_order_acquire);
+    while (slot[k].done.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
   }
   ~TailPool() {
     if (!started) return;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      stop = true;
-    }
+    stop.store(true);
     armed_until_ns.store(0);
-    cv.notify_all();
-    for (auto& t : th)
-      if (t.joinable()) t.join();
+    for (Slot& sl : slot) {
+      {
+        std::lock_guard<std::mutex> lk(sl.mu);
+        sl.cv.notify_one();
+      }
+      if (sl.th.joinable()) sl.th.join();
+    }
   }
 };
 
@@ -1757,11 +1849,19 @@ struct msm377_ctx {
   uint32_t last_wc = 0;
   int last_form = -1;  // MSM377_STAGE_FORM_* of the buckets the last call left (stage read-backs)
   bool capture = false;
-  bool timing = false;
+  int timing = 0;  // msm377_ctx_set_timing: 0 off, 1 every stage, 2 the accumulation kernel only
   // First reduction level run with one addition per lane quad.  0 = automatic: the first level whose 4 lanes x additions
   // x windows fit one wave per SIMD (65536 lanes) -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from
   // there on, slower before), 6 for 8, 4 for the 2 windows a rank of an 8-GPU run owns.  MSM377_COOP_FROM forces it (15 = never).
   uint32_t coop_from = 0;
+  // MSM377_COOP_THREADS: a tree level runs one lane quad per addition once that takes at most this many threads.  65536 / 131072 /
+  // 262144 make no difference on the main path (2^20: 2.74 ms each); on the narrow path 131072 moves its levels 0-2 to quads.
+  uint32_t coop_threads = 131072;
+  // MSM377_NARROW_TAIL_FROM: tail_from of the narrow-window path (2048 buckets per window).  Reduce stage at 2^12 with
+  // 7 / 5 / 4 / 3 / 2: 0.106 / 0.099 / 0.096 / 0.101 / 0.122 ms (profiles/r02_final/ab_narrow_tree.txt).
+  uint32_t narrow_tail_from = 4;
+  uint32_t narrow_seg = NARROW_SEG;  // MSM377_NARROW_SEG (>= NARROW_SEG: the buffers are sized for that)
+  int narrow_quad_acc = 1;         // MSM377_NARROW_QUAD_ACC=0: the narrow-window path accumulates with a thread per work item, like the main path
   // First level of the single-launch tail of the reduction (k_reduce_tail); MSM377_TAIL_FROM, 15 = one launch per level throughout.
   uint32_t tail_from = 7;  // measured (tools/ab_knobs.py, 2^20): 15: 2.874 ms, 7: 2.842, 6: 2.885, 5: 2.916, 4: 3.062
   // GLV front end of the Weierstrass path: 0 = off (default), 1 = on.  phi(P) = [lambda] P holds only for points of
@@ -1880,11 +1980,12 @@ struct StageTimer {  // HIP events around one stage of one part, on the part's o
   int s;
   hipStream_t st;
   uint32_t part;
+  bool on() const { return c->timing == 1 || (c->timing == 2 && s == MSM377_STAGE_ACC_KERNEL); }
   StageTimer(msm377_ctx* ctx, int stage, hipStream_t stream, uint32_t part_) : c(ctx), s(stage), st(stream), part(part_) {
-    if (c->timing) (void)hipEventRecord(c->ev[part][s][0], st);
+    if (on()) (void)hipEventRecord(c->ev[part][s][0], st);
   }
   ~StageTimer() {
-    if (c->timing) (void)hipEventRecord(c->ev[part][s][1], st);
+    if (on()) (void)hipEventRecord(c->ev[part][s][1], st);
   }
 };
 
@@ -1895,12 +1996,12 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, uint64_t f
   // k_accumulate waits for `bases_ready`.  Every entry point ends with a host-side wait for the
   // main stream, so the previous call's readers of d_bases are done.
   if (n == 0) return MSM377_OK;
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
+  if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_convert_bases<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases + first * CV::REC_WORDS, n,
                      ctx->d_err + 2);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
+  if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
   return MSM377_OK;
 }
@@ -1931,7 +2032,7 @@ inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POI
 int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, const uint32_t* prev_window_records = nullptr, bool clear_err = true) {
   if (n == 0) return MSM377_OK;
   const uint32_t nblk = affine_blocks(n);
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
+  if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   __atomic_store_n(ctx->h_aff_flag, 0u, __ATOMIC_RELEASE);
   if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   if (prev_window_records)
@@ -1981,7 +2082,7 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
   if (behind_sort && ctx->aff_down_after_sort) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->sort_done, 0));
   hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
+  if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
   return MSM377_OK;
 }
@@ -2046,7 +2147,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // per launch: each part must fill the GPU on its own.  Narrow windows: a small input is all latency -- a work item is
   // a serial chain of ~10 us additions -- so its chains are cut at 8 entries (the buffers, sized for 16 windows of
   // 2^15 rows plus entries / SEG_MIN items, hold the 23 x 2^11 rows and 23 n / 8 items of an input this small easily).
-  const uint32_t SEG = (narrow && !ctx->seg_plain) ? NARROW_SEG : auto_seg(ctx, (uint64_t)wc * n, glv);
+  const uint32_t SEG = (narrow && !ctx->seg_plain) ? ctx->narrow_seg : auto_seg(ctx, (uint64_t)wc * n, glv);
   uint16_t* digits = ctx->d_digits + (size_t)pv.ws0 * n;
   uint32_t* range_counts = ctx->d_range_counts + (size_t)part * NRANGE * (MAX_SORT_BLOCKS / 2);
   uint32_t* region_base = ctx->d_region_base + (size_t)pv.ws0 * (NRANGE + 1);
@@ -2127,7 +2228,16 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     {
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL, st, part);
       const dim3 grid((unsigned)((max_items + 255) / 256));
-      if constexpr (!std::is_same<BP, CV>::value)
+      bool launched = false;
+      if constexpr (std::is_same<BP, CV>::value && std::is_same<CV, TeDev>::value) {
+        if (narrow && ctx->narrow_quad_acc && !ph.table) {  // a lane quad per work item: the launch is one chain's latency
+          hipLaunchKernelGGL(k_accumulate_quad<CV>, dim3((unsigned)((4 * max_items + 255) / 256)), dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total,
+                             row_ovf_base, ovf, SEG, d_err, ctx->d_err + 2, ph.into ? 1u : 0u, L);
+          launched = true;
+        }
+      }
+      if (launched) {
+      } else if constexpr (!std::is_same<BP, CV>::value)
         hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
                            ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
       else
@@ -2169,11 +2279,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     const uint32_t first_level = 0;
     uint32_t coop_from = ctx->coop_from;
     if (coop_from == 0)
-      for (coop_from = 1; coop_from < levels && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > 65536; coop_from++) {
+      for (coop_from = 0; coop_from < levels && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > ctx->coop_threads; coop_from++) {
       }
     // Levels [0, coop_from): one thread per addition (VALU-bound: 2^18 additions per level at first); [coop_from,
     // tail_from): one lane quad per addition, one launch per level; [tail_from, levels): k_reduce_tail, one launch.
-    const uint32_t tail_from = CV::HAS_QUAD ? std::min(ctx->tail_from, levels) : levels;
+    const uint32_t tail_from = CV::HAS_QUAD ? std::min(narrow ? ctx->narrow_tail_from : ctx->tail_from, levels) : levels;
     // (Fusing pairs of thread-level levels -- four buckets a quarter-list apart per thread, four additions, three
     // stores -- halves their HBM traffic and was slower all the same: reduce 0.290 -> 0.310 ms at 2^20, 0.278 -> 0.296
     // at 2^16.  The first levels are VALU-bound at two waves per SIMD, the later ones cost one addition's latency
@@ -2263,6 +2373,10 @@ int finish_windows(msm377_ctx* ctx, int slot) {
   if (ctx->timing) {
     for (int s = 0; s < MSM377_NUM_STAGES; s++) {
       if (s == MSM377_STAGE_TAIL) continue;  // host wall time, set by the caller
+      if (ctx->timing == 2 && s != MSM377_STAGE_ACC_KERNEL) {
+        ctx->stage_ms[s] = 0.0;
+        continue;
+      }
       double sum = 0.0;  // a pipelined call reports the sum over its two parts (they overlap each other in wall time)
       for (uint32_t p = 0; p < (s == MSM377_STAGE_CONVERT ? 1u : ctx->last_parts); p++) {
         float ms = 0.f;
@@ -2292,11 +2406,11 @@ inline bool use_glv(const msm377_ctx* ctx, uint64_t) { return ctx->glv_mode == 1
 int convert_bases_g1(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, bool glv) {
   if (!glv) return convert_bases<G1Dev>(ctx, d_raw, n);
   if (n == 0) return MSM377_OK;
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
+  if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_convert_bases_glv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream2, d_raw, ctx->d_bases, n);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
+  if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
   return MSM377_OK;
 }
@@ -2638,6 +2752,10 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
+  if (const char* e = getenv("MSM377_NARROW_SEG")) ctx->narrow_seg = (uint32_t)std::min(std::max(atoi(e), (int)NARROW_SEG), (int)SEG_BINS - 1);
+  if (const char* e = getenv("MSM377_NARROW_QUAD_ACC")) ctx->narrow_quad_acc = atoi(e);
+  if (const char* e = getenv("MSM377_COOP_THREADS")) ctx->coop_threads = (uint32_t)atoi(e);
+  if (const char* e = getenv("MSM377_NARROW_TAIL_FROM")) ctx->narrow_tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
   if (const char* e = getenv("MSM377_TAIL_FROM")) ctx->tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
   const uint64_t cap = max_points;
   // The main stream outranks the side stream: the base conversion (VALU-heavy, ~0.2 ms) only has to finish before
@@ -2979,7 +3097,7 @@ int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint
     return MSM377_OK;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->timing) {  // no conversion in this mode
+  if (ctx->timing == 1) {  // no conversion in this mode
     (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream);
     (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream);
   }
@@ -3289,7 +3407,7 @@ int msm377_ctx_set_narrow_max(msm377_ctx* ctx, uint64_t max_points) {
 
 int msm377_ctx_set_timing(msm377_ctx* ctx, int enabled) {
   if (!ctx) return MSM377_EINVAL;
-  ctx->timing = enabled != 0;
+  ctx->timing = enabled == 2 ? 2 : (enabled != 0);
   return MSM377_OK;
 }
 

@@ -368,8 +368,10 @@ class MsmEngine:
         self._check(self._lib.msm377_ctx_set_glv(self._ctx, m), "msm377_ctx_set_glv")
 
     # -- measurement --
-    def set_timing(self, enabled: bool = True):
-        self._check(self._lib.msm377_ctx_set_timing(self._ctx, int(bool(enabled))), "msm377_ctx_set_timing")
+    def set_timing(self, enabled=True):
+        """True / 1: HIP events around every stage; 2: around the accumulation kernel only (the other stages read 0);
+        False / 0: off.  The events cost GPU idle time between the launches (~50 us per MSM with every stage on)."""
+        self._check(self._lib.msm377_ctx_set_timing(self._ctx, 2 if enabled == 2 else int(bool(enabled))), "msm377_ctx_set_timing")
 
     def stage_ms(self) -> dict:
         arr = (ctypes.c_double * len(STAGE_NAMES))()
