@@ -31,6 +31,8 @@
 //   buckets  W x NB records of 256 bytes, point-major: four 64-byte coordinate slots (13 limbs + 3 zero words);
 //            bucket t (key t + 1) of window slot w at record w * NB + t -- one lane writes whole lines
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1608,23 +1610,46 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
 // HOST TAIL's format: each coordinate re-based from the device's Montgomery radix 2^(29 NL) to
 // 2^(32 NW32) and written as NW32 little-endian u32 words, so the host does no conversion
 // multiplications.  One thread per (window slot, point, coordinate).
+//
+// host_out != nullptr: the records ALSO go straight into the caller's pinned host buffer (zero-copy stores over PCIe,
+// 50-80 KB), and the block that finishes last copies the call's error word next to a sequence number the host is
+// polling for (host_flag[0] = seq, host_flag[1] = error word) -- instead of two hipMemcpyAsync and an event, whose
+// copy-engine hand-over and completion signal cost ~25 us at the very end of every MSM.
 template <class CV>
-__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t wc, uint32_t L) {
+__global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t wc, uint32_t L,
+                                                      uint32_t* __restrict__ host_out = nullptr, uint32_t* host_flag = nullptr,
+                                                      uint32_t* dev_count = nullptr, const int* d_err = nullptr, uint32_t seq = 0) {
   const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= wc * MSM377_G1_PARTIAL_POINTS * 4) return;
   const uint32_t coord = g & 3, pt = (g >> 2) % MSM377_G1_PARTIAL_POINTS, ws = g / (4 * MSM377_G1_PARTIAL_POINTS);
-  if (pt > L) return;  // narrow windows have fewer bit planes; the host tail never reads the unused points
-  const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
-  typename CV::F::El v;
+  // narrow windows have fewer bit planes; the host tail never reads the unused points
+  if (g < wc * MSM377_G1_PARTIAL_POINTS * 4 && pt <= L) {
+    const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
+    typename CV::F::El v;
 #pragma unroll
-  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, L, ws, x)[coord * CV::COORD_WORDS + j];
-  v = CV::F::mul(v, CV::to64());
-  uint32_t w[CV::NW32];
-  CV::F::template to_words<CV::NW32>(v, w);
-  if (pt == 0 && coord == 0) w[CV::NW32 - 1] |= CV::RECORD_TAG;  // the record names its coordinate system (values are < 2^377: the bit is free)
-  uint32_t* o = out + ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
+    for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, L, ws, x)[coord * CV::COORD_WORDS + j];
+    v = CV::F::mul(v, CV::to64());
+    uint32_t w[CV::NW32];
+    CV::F::template to_words<CV::NW32>(v, w);
+    if (pt == 0 && coord == 0) w[CV::NW32 - 1] |= CV::RECORD_TAG;  // the record names its coordinate system (values are < 2^377: the bit is free)
+    const size_t at = ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
 #pragma unroll
-  for (uint32_t j = 0; j < CV::NW32; j++) o[j] = w[j];
+    for (uint32_t j = 0; j < CV::NW32; j++) out[at + j] = w[j];
+    if (host_out) {
+#pragma unroll
+      for (uint32_t j = 0; j < CV::NW32; j++) host_out[at + j] = w[j];
+    }
+  }
+  if (host_out) {  // a kernel argument: uniform
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(dev_count, 1u) == gridDim.x - 1) {  // every other block's records are on their way
+      __threadfence_system();
+      __hip_atomic_store(&host_flag[1], (uint32_t)__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      __hip_atomic_store(&host_flag[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      *dev_count = 0u;  // for the next call (stream order)
+    }
+  }
 }
 
 // Synthetic bases: P_i = [a_i]G with a_i the (i+1)-th SplitMix64(seed) output, wire format.
@@ -1727,10 +1752,46 @@ struct TailPool {
   bool started = false;
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   bool armed(int k) const { return k < armed_count.load(std::memory_order_relaxed) && now_ns() < armed_until_ns.load(std::memory_order_relaxed); }
+  // The logical CPUs of the NUMA node the calling thread runs on (false: unknown).  The workers are kept on that node:
+  // on a two-socket host a worker on the far socket reads the records and its job across the socket link.  (Why: the
+  // tail stage was bimodal from one context to the next on some boxes, 0.077 / 0.112 ms; an A/B of 8 contexts each
+  // way on another box showed 0.075-0.079 for all of them, so the cause is a hypothesis, not a measurement.)
+  static bool local_node_cpus(cpu_set_t* set) {
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return false;
+    for (int node = 0; node < 64; node++) {
+      char path[96];
+      snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+      FILE* f = fopen(path, "r");
+      if (!f) break;
+      char buf[4096];
+      const bool got = fgets(buf, sizeof buf, f) != nullptr;
+      fclose(f);
+      if (!got) continue;
+      CPU_ZERO(set);
+      bool mine = false;
+      for (char* p = buf; *p;) {  // "0-63,128-191"
+        char* e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET((int)c, set);
+        mine |= cpu >= a && cpu <= b;
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+      }
+      if (mine) return true;
+    }
+    return false;
+  }
+  bool numa_local = true;  // MSM377_TAIL_NUMA=0: leave the workers where the scheduler puts them
   void start() {
     if (started) return;
     started = true;
-    for (int k = 0; k < WORKERS; k++)
+    cpu_set_t node_cpus;
+    const bool pin = numa_local && local_node_cpus(&node_cpus);
+    for (int k = 0; k < WORKERS; k++) {
       slot[k].th = std::thread([this, k] {
         Slot& me = slot[k];
         uint64_t seen = 0;
@@ -1751,6 +1812,8 @@ struct TailPool {
           me.done.store(seen, std::memory_order_release);
         }
       });
+      if (pin) (void)pthread_setaffinity_np(slot[k].th.native_handle(), sizeof node_cpus, &node_cpus);
+    }
   }
   void wake(Slot& sl) {
     if (!sl.asleep.load()) return;
@@ -1849,6 +1912,14 @@ struct msm377_ctx {
   uint32_t last_wc = 0;
   int last_form = -1;  // MSM377_STAGE_FORM_* of the buckets the last call left (stage read-backs)
   bool capture = false;
+  // Zero-copy output of the full-MSM path (k_gather_partials, wait_zero_copy_out); MSM377_ZERO_COPY_OUT=0: D2H copies + event.
+  int zc_out = 1;
+  bool zc_active = false;         // the call being enqueued / waited for uses it
+  uint32_t out_seq = 0;           // sequence number of the last zero-copy call
+  uint32_t* h_out_flag = nullptr; // pinned: [0] sequence number, [1] error word
+  uint32_t* dm_out_flag = nullptr;
+  uint32_t* dm_partials = nullptr;  // device address of h_partials
+  uint32_t* d_out_count = nullptr;
   int timing = 0;  // msm377_ctx_set_timing: 0 off, 1 every stage, 2 the accumulation kernel only
   // First reduction level run with one addition per lane quad.  0 = automatic: the first level whose 4 lanes x additions
   // x windows fit one wave per SIMD (65536 lanes) -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from
@@ -2117,6 +2188,7 @@ struct Phase {
   bool front = true;       // decompose .. merge
   bool into = false;       // accumulate on top of the buckets of an earlier chunk
   bool back = true;        // bucket reduction, gather, D2H, completion event
+  bool zc_out = false;     // the gather kernel writes the records and the error word into pinned host memory itself (k_gather_partials)
   uint64_t base_first = 0; // first record of ctx->d_bases this chunk's indices refer to
   // Precomputed-window tables (msm377_g1_set_bases_precomputed): window slot ws gathers from record ws * table_stride + i
   // of `table`, and because the table already carries the 2^(16 ws) weights the 16 bucket sets are ADDED together
@@ -2306,8 +2378,12 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
         HIP_TRY(ctx, hipGetLastError());
       }
     }
-    hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets,
-                       d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc, L);
+    if (ctx->zc_active)  // set by enqueue_windows for this call: one part, slot 0
+      hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets, d_partials, wc, L, ctx->dm_partials,
+                         ctx->dm_out_flag, ctx->d_out_count, (const int*)d_err, ctx->out_seq);
+    else
+      hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets,
+                         d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc, L);
     HIP_TRY(ctx, hipGetLastError());
   }
   return MSM377_OK;
@@ -2346,6 +2422,8 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->part_fork, 0));
   }
   ctx->last_parts = parts;
+  ctx->zc_active = ph.zc_out && ph.back && ctx->zc_out && parts == 1 && slot == 0 && !ph.table;
+  if (ctx->zc_active) ctx->out_seq++;
   for (uint32_t p = 0; p < parts; p++) {
     int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS, part_phase);
     if (rc) return rc;
@@ -2356,9 +2434,11 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->part_join, 0));
   }
   const uint32_t wc_out = ph.table ? 1u : wc;  // precomputed-window tables fold the windows on the GPU
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc_out * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
-                               hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err + slot, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (!ctx->zc_active) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc_out * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
+                                 hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err + slot, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->done_ev[slot], st));
   ctx->last_n = n;
   ctx->last_wc = wc;
@@ -2368,8 +2448,34 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
 }
 
 // Wait for slot `slot`; its partial records are then in ctx->h_partials + slot * SLOT_WORDS.
+// Zero-copy output (Phase::zc_out): poll the sequence number the gather kernel's last block writes behind the records;
+// the stream's completion event is waited for only when stage timing needs it (or after 50 ms without the flag, which
+// then also surfaces a failed kernel).
+int wait_zero_copy_out(msm377_ctx* ctx) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spins = 0; __atomic_load_n(&ctx->h_out_flag[0], __ATOMIC_ACQUIRE) != ctx->out_seq; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+      break;
+    }
+  }
+  if (__atomic_load_n(&ctx->h_out_flag[0], __ATOMIC_ACQUIRE) != ctx->out_seq) {
+    ctx->err = "zero-copy output: the window records did not arrive";
+    return MSM377_EHIP;
+  }
+  ctx->h_err[0] = (int)__atomic_load_n(&ctx->h_out_flag[1], __ATOMIC_RELAXED);
+  return MSM377_OK;
+}
+
 int finish_windows(msm377_ctx* ctx, int slot) {
-  HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
+  if (ctx->zc_active && slot == 0) {
+    const int rc = wait_zero_copy_out(ctx);
+    if (rc) return rc;
+    if (ctx->timing) HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
+  } else {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[slot]));
+  }
   if (ctx->timing) {
     for (int s = 0; s < MSM377_NUM_STAGES; s++) {
       if (s == MSM377_STAGE_TAIL) continue;  // host wall time, set by the caller
@@ -2571,11 +2677,17 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
         cbits = NARROW_BITS;
         planes = NARROW_LOG;
       }
+      ph.zc_out = true;
       int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, windows, 0, false, ph)
                                 : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, windows, 0, false, ph);
       if (rc) return rc;
       arm.after_accumulation();
-      HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+      if (ctx->zc_active) {
+        rc = wait_zero_copy_out(ctx);
+        if (rc) return rc;
+      } else {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+      }
       if (narrow && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar >= 2^253: the 16-bit path takes it
         narrow = false;
         continue;
@@ -2742,6 +2854,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
   if (const char* e = getenv("MSM377_TAIL_SPIN_US")) ctx->tail_spin_us = atoll(e);
+  if (const char* e = getenv("MSM377_TAIL_NUMA")) ctx->tail_pool.numa_local = atoi(e) != 0;
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
@@ -2752,6 +2865,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
+  if (const char* e = getenv("MSM377_ZERO_COPY_OUT")) ctx->zc_out = atoi(e);
   if (const char* e = getenv("MSM377_NARROW_SEG")) ctx->narrow_seg = (uint32_t)std::min(std::max(atoi(e), (int)NARROW_SEG), (int)SEG_BINS - 1);
   if (const char* e = getenv("MSM377_NARROW_QUAD_ACC")) ctx->narrow_quad_acc = atoi(e);
   if (const char* e = getenv("MSM377_COOP_THREADS")) ctx->coop_threads = (uint32_t)atoi(e);
@@ -2810,7 +2924,13 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
        hipEventCreateWithFlags(&ctx->sort_done, hipEventDisableTiming) == hipSuccess;
   if (ok) ctx->aff_scratch.resize(aff_blocks);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
-  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * SLOT_WORDS * 4) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * SLOT_WORDS * 4, host_flags) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&ctx->dm_partials, ctx->h_partials, 0) == hipSuccess &&
+       hipHostMalloc((void**)&ctx->h_out_flag, 64, host_flags) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&ctx->dm_out_flag, ctx->h_out_flag, 0) == hipSuccess;
+  if (ok) memset(ctx->h_out_flag, 0, 64);
+  dalloc((void**)&ctx->d_out_count, 64);
+  ok = ok && hipMemset(ctx->d_out_count, 0, 64) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, 2 * sizeof(int)) == hipSuccess;
   for (int k = 0; ok && k < 2; k++) ok = ok && hipEventCreateWithFlags(&ctx->done_ev[k], hipEventDisableTiming) == hipSuccess;
   for (int s = 0; ok && s < MSM377_NUM_STAGES; s++)
@@ -2830,11 +2950,12 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_table};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->h_out_flag) (void)hipHostFree(ctx->h_out_flag);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_aff_prod) (void)hipHostFree(ctx->h_aff_prod);
   if (ctx->h_aff_inv) (void)hipHostFree(ctx->h_aff_inv);
