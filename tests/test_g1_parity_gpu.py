@@ -589,6 +589,43 @@ def test_window_sharding_on_one_gpu(engine, oracle, world):
     assert msm.combine_partials(b"".join(parts)) == util.oracle_msm(oracle, pts, ks)
 
 
+@pytest.mark.parametrize(
+    "knobs",
+    [
+        {"MSM377_NARROW_QUAD_ACC": "0"},  # narrow path with a thread per work item (k_accumulate), not a lane quad
+        {"MSM377_ZERO_COPY_OUT": "0"},  # D2H copies + event instead of the gather kernel's zero-copy stores
+        {"MSM377_TAIL_THREADS": "1"},
+        {"MSM377_TAIL_THREADS": "8", "MSM377_TAIL_SPIN_US": "0", "MSM377_TAIL_NUMA": "0"},
+        {"MSM377_TAIL_THREADS": "3"},
+        {"MSM377_NARROW_TAIL_FROM": "7", "MSM377_COOP_THREADS": "65536", "MSM377_NARROW_SEG": "32"},
+        {"MSM377_NARROW_TAIL_FROM": "1", "MSM377_COOP_THREADS": "100000000"},  # every level on lane quads, everything behind level 0 in one launch
+    ],
+    ids=lambda k: ",".join("%s=%s" % (a.replace("MSM377_", ""), b) for a, b in k.items()),
+)
+def test_alternative_settings_of_the_default_path(oracle, monkeypatch, knobs):
+    """The default path's build-time-equal alternatives (context knobs read from the environment) against the oracle on
+    both window geometries: the result does not depend on which of them runs.  Also the stage timing levels."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    eng = msm.MsmEngine(1 << 17)
+    try:
+        for n in (1, 7, 300, 4099, 40000, 100003):
+            pts, ks = seeded_inputs(oracle, n, 900 + n)
+            exp = util.oracle_msm(oracle, pts, ks)
+            d_p, d_s = dev(pts), dev(ks)
+            for timing in (False, 2, True):
+                eng.set_timing(timing)
+                assert eng.msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == exp, (n, timing)
+                st = eng.stage_ms()
+                if timing:
+                    assert st["accumulate_kernel"] > 0.0
+                    assert (st["reduce"] > 0.0) == (timing is True)
+            eng.set_timing(False)
+            assert eng.msm(pts, ks) == exp, n
+    finally:
+        eng.close()
+
+
 def test_host_buffers_upload_in_two_chunks(oracle, monkeypatch):
     """msm377_g1_msm with large host buffers uploads and accumulates in two chunks of points (chunk B on top of chunk
     A's buckets, one reduction): forced here at small sizes through MSM377_UPLOAD_CHUNK_MIN; both coordinate forms,
