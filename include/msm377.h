@@ -190,8 +190,8 @@ int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
  * the window-partials entry points always use it. */
 int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form);
 
-/* Small inputs: G1 full-MSM calls of at most `max_points` points (default 2^15, at most 2^16; 0 = never) run with
- * 11-bit windows -- 23 windows of 2 048 buckets instead of 16 of 32 768: 0.46-0.60 instead of 0.64-0.73 ms -- the
+/* Small inputs: G1 full-MSM calls of at most `max_points` points (default and at most 2^16; 0 = never) run with
+ * 11-bit windows -- 23 windows of 2 048 buckets instead of 16 of 32 768: 0.24-0.56 instead of 0.53-0.60 ms -- the
  * counterpart of the reference's switch to narrower windows for small inputs (src/submission/submission.ts:97: 4-bit
  * below 65 536 points).  Same results, same error conditions; scalars of 2^253 and more rerun on the 16-bit path. */
 int msm377_ctx_set_narrow_max(msm377_ctx* ctx, uint64_t max_points);

@@ -6,7 +6,7 @@
 // /root/reference/src/submission/):
 //   k_affine_up / host inversion / k_affine_down (n >= 2^20, resident tables), k_convert_bases (otherwise)
 //                     wire x||y -> Montgomery records            wgsl/cuzk/convert_point_coords_and_decompose_scalars.template.wgsl:41-99 + barrett.template.wgsl:60-82
-//   k_decompose (16-bit windows), k_decompose_narrow (inputs <= 2^15 points: 11-bit windows, submission.ts:97)
+//   k_decompose (16-bit windows), k_decompose_narrow (inputs <= 2^16 points: 11-bit windows, submission.ts:97)
 //                     scalars -> signed digits                   same file :100-141; model cuzk/utils.ts:66-109
 //   k_range_count / k_range_scan / k_partition / k_local_sort (k_small_sort on the narrow path)
 //                     per-window counting sort -> CSR            wgsl/cuzk/transpose_serial.wgsl:34-76 (16 serial threads there); model cuzk/transpose.ts:14-62
@@ -1932,6 +1932,7 @@ struct msm377_ctx {
   // 7 / 5 / 4 / 3 / 2: 0.106 / 0.099 / 0.096 / 0.101 / 0.122 ms (profiles/r02_final/ab_narrow_tree.txt).
   uint32_t narrow_tail_from = 4;
   uint32_t narrow_seg = NARROW_SEG;  // MSM377_NARROW_SEG (>= NARROW_SEG: the buffers are sized for that)
+  uint64_t narrow_quad_items = 100000;  // MSM377_NARROW_QUAD_ITEMS: most work items k_accumulate_quad is used for
   int narrow_quad_acc = 1;         // MSM377_NARROW_QUAD_ACC=0: the narrow-window path accumulates with a thread per work item, like the main path
   // First level of the single-launch tail of the reduction (k_reduce_tail); MSM377_TAIL_FROM, 15 = one launch per level throughout.
   uint32_t tail_from = 7;  // measured (tools/ab_knobs.py, 2^20): 15: 2.874 ms, 7: 2.842, 6: 2.885, 5: 2.916, 4: 3.062
@@ -1962,14 +1963,16 @@ struct msm377_ctx {
   // six sleeping workers 0.124, six polling ones 0.089.  (Round 2 first measured no difference: the per-thread
   // exceptional-case flags shared a cache line then and the threads fought over it -- TeChecked is padded now.)
   int64_t tail_spin_us = 1000;
+  bool tail_trace = false;  // MSM377_TAIL_TRACE=1
   int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
   uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
   int last_products = 0;        // field products per bucket addition of the last accumulation launch (bench.py's int32-mad roof)
   // Inputs of at most this many points run the narrow-window path (11-bit windows: 23 x 2048 buckets instead of
   // 16 x 32768; MSM377_NARROW_MAX, 0 = never).  Interleaved A/B, 16-bit / narrow ms per MSM (tools/ab_knobs.py):
-  // 2^10 0.64 / 0.46, 2^13 0.67 / 0.53, 2^14 0.68 / 0.51, 2^15 0.73 / 0.60, 2^16 0.74 / 0.71.
-  uint64_t narrow_max_points = 1ull << 15;
+  // 2^10 0.64 / 0.46, 2^13 0.67 / 0.53, 2^14 0.68 / 0.51, 2^15 0.73 / 0.60, 2^16 0.74 / 0.71 (first version); at the end of
+  // round 2: 2^16 0.605 / 0.56 (its bucket reduction 0.28 / 0.10 ms, its accumulation kernel 0.14 / 0.18), hence 2^16.
+  uint64_t narrow_max_points = 1ull << 16;
   uint64_t fallback_count = 0;  // reruns on the Weierstrass path after an exceptional case of the Edwards law
   uint32_t fallback_mask = 0;   // MSM377_FB_* bits of the last one
 };
@@ -2302,7 +2305,9 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       const dim3 grid((unsigned)((max_items + 255) / 256));
       bool launched = false;
       if constexpr (std::is_same<BP, CV>::value && std::is_same<CV, TeDev>::value) {
-        if (narrow && ctx->narrow_quad_acc && !ph.table) {  // a lane quad per work item: the launch is one chain's latency
+        // a lane quad per work item while the launch is one chain's latency (up to 2^14 points: ~94 k items); beyond that
+        // the quads are VALU-bound like threads and only add their exchange instructions (kernel at 2^16: 0.216 / 0.183 ms)
+        if (narrow && ctx->narrow_quad_acc && !ph.table && max_items <= ctx->narrow_quad_items) {
           hipLaunchKernelGGL(k_accumulate_quad<CV>, dim3((unsigned)((4 * max_items + 255) / 256)), dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total,
                              row_ovf_base, ovf, SEG, d_err, ctx->d_err + 2, ph.into ? 1u : 0u, L);
           launched = true;
@@ -2583,11 +2588,20 @@ Pt tail_horner_mt(msm377_ctx* ctx, RangeFn range, DblFn dbl, DblNtFn dbl_nt, Add
   TailPool& pool = ctx->tail_pool;
   if (used > 1) pool.start();
   Pt part[MAXC];
-  auto chain = [&part, &bounds, range, dbl, dbl_nt](int k) {
+  // MSM377_TAIL_TRACE=1: per-piece start / end (us after the call) and CPU, on stderr
+  const bool trace = ctx->tail_trace;
+  const int64_t t_call = trace ? TailPool::now_ns() : 0;
+  struct alignas(128) Mark {
+    int64_t t0, t1;
+    int cpu;
+  } mark[MAXC];
+  auto chain = [&part, &bounds, &mark, trace, range, dbl, dbl_nt](int k) {
+    if (trace) mark[k].t0 = TailPool::now_ns(), mark[k].cpu = sched_getcpu();
     Pt acc = range(bounds[k], bounds[k + 1], k);
     for (int i = 0; i + 1 < bounds[k]; i++) acc = dbl_nt(acc, k);
     if (bounds[k] > 0) acc = dbl(acc, k);
     part[k] = acc;
+    if (trace) mark[k].t1 = TailPool::now_ns();
   };
   for (int k = 0; k + 1 < used; k++) pool.post(k, [&chain, k] { chain(k); });
   chain(used - 1);  // the top piece: the fewest positions, the most doublings
@@ -2595,6 +2609,11 @@ Pt tail_horner_mt(msm377_ctx* ctx, RangeFn range, DblFn dbl, DblNtFn dbl_nt, Add
   for (int k = used - 2; k >= 0; k--) {
     pool.wait(k);
     acc = add(acc, part[k], used - 1);
+  }
+  if (trace) {
+    fprintf(stderr, "tail trace:");
+    for (int k = 0; k < used; k++) fprintf(stderr, "  [%d cpu %d: %.1f..%.1f]", k, mark[k].cpu, (mark[k].t0 - t_call) / 1e3, (mark[k].t1 - t_call) / 1e3);
+    fprintf(stderr, "  done %.1f us\n", (TailPool::now_ns() - t_call) / 1e3);
   }
   return acc;
 }
@@ -2645,17 +2664,29 @@ void time_tail(msm377_ctx* ctx, std::chrono::steady_clock::time_point t0) {
 // jobs while the GPU reduces the buckets); disarmed when the tail is done.
 struct TailArm {
   msm377_ctx* c;
+  bool armed = false;
   explicit TailArm(msm377_ctx* ctx) : c(ctx) {}
-  void after_accumulation() {
-    if (c->tail_threads <= 1 || c->tail_spin_us <= 0) return;
-    if (hipEventSynchronize(c->acc_done) != hipSuccess) return;  // the caller's own wait reports the error
+  void arm() {
+    if (armed || c->tail_threads <= 1 || c->tail_spin_us <= 0) return;
+    armed = true;
     c->tail_pool.prewake(c->tail_spin_us, std::min(c->tail_threads, TailPool::WORKERS + 1) - 1);
+  }
+  // A small input is over in a few hundred microseconds, its bucket reduction in 0.1 ms -- no longer than a sleeping
+  // worker may take to come back -- so its call arms the workers before it enqueues anything.
+  void at_start(uint64_t n) {
+    if (n <= (1ull << 17)) arm();
+  }
+  void after_accumulation() {
+    if (armed || c->tail_threads <= 1 || c->tail_spin_us <= 0) return;
+    if (hipEventSynchronize(c->acc_done) != hipSuccess) return;  // the caller's own wait reports the error
+    arm();
   }
   ~TailArm() { c->tail_pool.disarm(); }
 };
 
 int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int form, uint8_t out_xy[96]) {
   TailArm arm(ctx);
+  arm.at_start(n);
   if (form_is_te(form)) {
     Phase ph;
     if (form == TABLE_TE_PRECOMP) {
@@ -2854,6 +2885,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = atoi(e);
   if (const char* e = getenv("MSM377_TAIL_SPIN_US")) ctx->tail_spin_us = atoll(e);
+  if (const char* e = getenv("MSM377_TAIL_TRACE")) ctx->tail_trace = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_NUMA")) ctx->tail_pool.numa_local = atoi(e) != 0;
   if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
@@ -2867,6 +2899,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   if (const char* e = getenv("MSM377_ZERO_COPY_OUT")) ctx->zc_out = atoi(e);
   if (const char* e = getenv("MSM377_NARROW_SEG")) ctx->narrow_seg = (uint32_t)std::min(std::max(atoi(e), (int)NARROW_SEG), (int)SEG_BINS - 1);
+  if (const char* e = getenv("MSM377_NARROW_QUAD_ITEMS")) ctx->narrow_quad_items = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_NARROW_QUAD_ACC")) ctx->narrow_quad_acc = atoi(e);
   if (const char* e = getenv("MSM377_COOP_THREADS")) ctx->coop_threads = (uint32_t)atoi(e);
   if (const char* e = getenv("MSM377_NARROW_TAIL_FROM")) ctx->narrow_tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
@@ -3093,7 +3126,10 @@ int msm377_ed_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_sc
   rc = convert_bases<EdDev>(ctx, (const uint32_t*)d_points, n);
   if (rc) return rc;
   TailArm arm(ctx);
-  rc = enqueue_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS, 0);
+  arm.at_start(n);
+  Phase ph;
+  ph.zc_out = true;
+  rc = enqueue_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
   if (rc) return rc;
   arm.after_accumulation();
   rc = finish_windows(ctx, 0);

@@ -351,7 +351,7 @@ class MsmEngine:
         """Coordinate system of the captured buckets: 0 = Weierstrass XYZZ, 1 = twisted Edwards (X, Y, T, Z), -1 = none."""
         return int(self._lib.msm377_ctx_get_stage_form(self._ctx))
 
-    def set_narrow_max(self, max_points: int = 1 << 15):
+    def set_narrow_max(self, max_points: int = 1 << 16):
         """Inputs of at most this many points run with 11-bit windows (msm377_ctx_set_narrow_max; 0 = never)."""
         self._check(self._lib.msm377_ctx_set_narrow_max(self._ctx, int(max_points)), "msm377_ctx_set_narrow_max")
 
