@@ -97,7 +97,13 @@ def self_launch(args, argv):
 def latest_pmc_summary():
     """(tag, summary) of the newest committed rocprofv3 PMC summary (profiles/rNN_*/pmc_summary.json)."""
     prof = os.path.join(ROOT, "profiles")
-    tags = sorted((d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "pmc_summary.json"))), reverse=True) if os.path.isdir(prof) else []
+    tags = [d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "pmc_summary.json"))] if os.path.isdir(prof) else []
+    # newest first: by round number, and within a round the pass named in profiles/LATEST (else the name, descending)
+    latest = ""
+    if os.path.exists(os.path.join(prof, "LATEST")):
+        with open(os.path.join(prof, "LATEST")) as f:
+            latest = f.read().strip()
+    tags.sort(key=lambda d: (d == latest, d.split("_")[0], d), reverse=True)
     for tag in tags:
         with open(os.path.join(prof, tag, "pmc_summary.json")) as f:
             return tag, json.load(f)

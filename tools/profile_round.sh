@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call -> everything profiles/<tag>/ needs (run from the repo root ON THE GPU BOX):
-#   bench.json               python bench.py --steps 20 --warmup 3   (free-running clocks, with the CPU baseline)
-#   kernel_stats.csv         rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu-baseline`
+#   bench.json               python bench.py   (default steps / warm-up, free-running clocks, with the CPU baseline)
+#   kernel_stats.csv         rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --no-cpu-baseline`
 #   bench_under_rocprof.log  the bench line printed inside that profiled run (its roofline.kernel_ms must agree)
 #   pmc_summary.json         three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM), tools/summarize_pmc.py
 # usage: tools/profile_round.sh <tag>
@@ -11,11 +11,11 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
-python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
-python3 bench.py --workload ed --steps 10 --warmup 2 > $out/bench_ed.json 2>> $out/bench.err
+python3 bench.py > $out/bench.json 2> $out/bench.err
+python3 bench.py --workload ed > $out/bench_ed.json 2>> $out/bench.err
 python3 bench.py --workload fixed64 --steps 2 --warmup 1 > $out/bench_fixed64.json 2>> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.log 2> $out/rocprof_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.log 2> $out/rocprof_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/rocprof_pmc1.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/rocprof_pmc2.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $out/pmc_sq -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/rocprof_pmc3.err
