@@ -2242,6 +2242,14 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // then measures window 15 of the plain front end.
   hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, meta_block, META_BLOCK_WORDS, (uint32_t*)d_err, (ph.clear_err && part == 0) ? 1u : 0u);
   uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
+  const uint64_t max_items = (uint64_t)wc * NB + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
+  // a lane quad per work item while the launch is one chain's latency (up to 2^14 points: ~94 k items); beyond that
+  // the quads are VALU-bound like threads and only add their exchange instructions (kernel at 2^16: 0.216 / 0.183 ms)
+  const bool quad_acc = std::is_same<BP, CV>::value && std::is_same<CV, TeDev>::value && narrow && ctx->narrow_quad_acc && !ph.table && max_items <= ctx->narrow_quad_items;
+  // (One launch for the whole front end of such a call -- each window's workgroup recoding, sorting and listing its
+  // work items itself, one global atomic per list and workgroup -- was built and dropped: 0.271 -> 0.293 ms at 2^12,
+  // 0.342 -> 0.373 at 2^14.  Saving four dispatch latencies did not pay for a work list that is sorted by length
+  // only within each window: the accumulation kernel went from 0.038 to 0.054 ms at 2^12.)
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (narrow)
@@ -2288,7 +2296,6 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work);
     HIP_TRY(ctx, hipGetLastError());
-    const uint64_t max_items = (uint64_t)rows + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
     if (ctx->before_accumulate) {  // must run before the wait below is queued: the wait binds to the event's latest record
       std::function<int()> f;
       f.swap(ctx->before_accumulate);
@@ -2305,9 +2312,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       const dim3 grid((unsigned)((max_items + 255) / 256));
       bool launched = false;
       if constexpr (std::is_same<BP, CV>::value && std::is_same<CV, TeDev>::value) {
-        // a lane quad per work item while the launch is one chain's latency (up to 2^14 points: ~94 k items); beyond that
-        // the quads are VALU-bound like threads and only add their exchange instructions (kernel at 2^16: 0.216 / 0.183 ms)
-        if (narrow && ctx->narrow_quad_acc && !ph.table && max_items <= ctx->narrow_quad_items) {
+        if (quad_acc) {
           hipLaunchKernelGGL(k_accumulate_quad<CV>, dim3((unsigned)((4 * max_items + 255) / 256)), dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total,
                              row_ovf_base, ovf, SEG, d_err, ctx->d_err + 2, ph.into ? 1u : 0u, L);
           launched = true;
@@ -2495,6 +2500,7 @@ int finish_windows(msm377_ctx* ctx, int slot) {
       }
       ctx->stage_ms[s] = sum;
     }
+    (void)hipGetLastError();  // a stage that did not run in this call must not leave its error for the next launch check
   }
   if (ctx->h_err[slot] & ERR_SCALAR) {
     ctx->err = "a scalar overflows the signed 16-bit window recode (final carry)";
