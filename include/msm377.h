@@ -120,6 +120,11 @@ int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count);
  * the ranks) into the final affine result: Horner over the windows, one field inversion.
  * Host-only; needs no context and no device (replaces the CPU tail, submission.ts:290-321). */
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
+/* The same result for records in twisted Edwards form, computed the way a context's tail threads compute it -- the
+ * Horner chain cut into `pieces` (1..64) balanced pieces, each doubled up to its position, then added -- but on the
+ * calling thread: the decomposition of msm377_g1_combine_partials_ctx / the full-MSM entry points, checkable without a
+ * GPU (tests/test_host_tail.py).  MSM377_EINVAL for records in Weierstrass form. */
+int msm377_g1_combine_partials_split(const uint8_t* partials, uint32_t pieces, uint8_t out_xy[96]);
 /* The same on the context's tail threads (four Horner chains, as inside msm377_g1_msm): 0.12 instead of 0.18 ms. */
 int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uint8_t out_xy[96]);
 

@@ -133,3 +133,41 @@ def test_edwards_tail_reports_exceptional_cases():
     split = b"".join(record(win[w], rnd) if w == 0 else te_record(win[w], rnd) for w in range(16))
     assert msm.combine_partials(split) == expect
     assert msm.combine_partials(b"".join(record(win[w], rnd) for w in range(16))) == expect
+
+
+def test_tail_in_pieces_matches_the_single_chain():
+    """The threaded host tail cuts the 256-position Horner chain into balanced pieces (csrc/fp64_host.hpp tail_split,
+    teh_tail_piece; doublings without T between the pieces) and adds them up.  msm377_g1_combine_partials_split runs that
+    decomposition on the calling thread: every piece count gives the single chain's answer, which is the definition's;
+    and an exceptional case inside one piece is still reported."""
+    from webgpu_msm_bls12_377_amd.host.engine import EEXCEPTIONAL, combine_partials_split_bytes
+
+    rnd = random.Random(31)
+    base = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(9)]
+    win_pts, expect = [], None
+    for w in range(16):
+        pts16 = [rnd.choice(base + [None]) for _ in range(16)]
+        win_pts.append(pts16)
+        g = pts16[0]
+        for l in range(15):
+            g = R.add(g, R.mul(pts16[1 + l], 1 << l))
+        expect = R.add(expect, R.mul(g, 1 << (16 * w)))
+    recs = b"".join(te_record(win_pts[w], rnd) for w in range(16))
+    exp = R.encode_result(expect)
+    assert msm.combine_partials(recs) == exp
+    for pieces in (1, 2, 3, 4, 5, 6, 7, 8, 13, 64):
+        assert combine_partials_split_bytes(recs, pieces) == exp, pieces
+    # Weierstrass records: not this entry point's business
+    with pytest.raises(msm.MsmError):
+        combine_partials_split_bytes(b"".join(record(win_pts[w], rnd) for w in range(16)), 4)
+    # the exceptional pair of test_edwards_tail_reports_exceptional_cases: caught whichever piece holds it
+    tp = util.t_prime()
+    c = R.mul(R.G, 777)
+    a = R.add(R.mul(c, 1 << 16), tp)
+    win = [[None] * 16 for _ in range(16)]
+    win[0][0], win[1][0] = a, c
+    bad = b"".join(te_record(win[w], rnd) for w in range(16))
+    for pieces in (1, 2, 6, 8):
+        with pytest.raises(msm.MsmError) as e:
+            combine_partials_split_bytes(bad, pieces)
+        assert e.value.code == EEXCEPTIONAL, pieces

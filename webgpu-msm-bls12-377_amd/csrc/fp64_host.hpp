@@ -4,6 +4,7 @@
 // src/submission/submission.ts:290-321 and cuzk/bls12_377.ts:41-63).  Same static interface
 // as Field<> in field29.hpp so G1T<> / EdT<> work over it.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -441,6 +442,58 @@ inline TeH::Ext teh_horner_bits(const uint32_t* partials, int lo, int hi, TeChec
 inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
   return teh_horner_bits(partials, 0, cbits * num_windows, chk, skip_windows, cbits, planes);
 }
+inline int imin(int a, int b) { return a < b ? a : b; }
+// ---- the tail in pieces (msm377.hip tail_horner_mt runs them on threads) ----
+// The Horner chain over `positions` bit positions cut into at most `chains` pieces: the piece that owns positions
+// [lo, hi) costs (hi - lo) steps of doubling + addition (~17 field products each) and then `lo` doublings (~7 each);
+// the cuts balance that sum, so the pieces shrink towards the top.  bounds[0 .. used]; returns used <= chains.
+constexpr double TAIL_STEP_COST = 17.0, TAIL_DBL_COST = 7.0;
+inline int tail_split(int positions, int chains, int* bounds) {
+  double lo = 0.0, hi = positions * TAIL_STEP_COST;
+  auto reach = [&](double t) {
+    double o = 0.0;
+    for (int k = 0; k < chains; k++) o += fmax(0.0, (t - TAIL_DBL_COST * o) / TAIL_STEP_COST);
+    return o;
+  };
+  for (int it = 0; it < 48; it++) {
+    const double t = 0.5 * (lo + hi);
+    (reach(t) >= positions ? hi : lo) = t;
+  }
+  int used = 0;
+  double o = 0.0;
+  bounds[0] = 0;
+  for (int k = 0; k < chains && bounds[used] < positions; k++) {
+    o += fmax(0.0, (hi - TAIL_DBL_COST * o) / TAIL_STEP_COST);
+    const int b = k + 1 == chains ? positions : imin(positions, (int)(o + 0.5));
+    if (b > bounds[used]) bounds[++used] = b;
+  }
+  bounds[used] = positions;
+  return used;
+}
+
+// One piece: sum of the records of positions [lo, hi) x 2^(position), i.e. its own Horner chain and then `lo` doublings
+// (all but the last without T: nothing reads it before the next doubling).
+inline TeH::Ext teh_tail_piece(const uint32_t* partials, int lo, int hi, TeChecked& chk, int cbits = 16, int planes = 15) {
+  TeH::Ext acc = teh_horner_bits(partials, lo, hi, chk, 0, cbits, planes);
+  for (int i = 0; i + 1 < lo; i++) acc = chk.dbl_nt(acc);
+  if (lo > 0) acc = chk.dbl(acc);
+  return acc;
+}
+// The same tail as teh_combine, computed the way the threaded tail does -- `chains` pieces, added up -- on the calling
+// thread (msm377_g1_combine_partials_split: the CPU tests' view of that decomposition).
+inline bool teh_combine_split(const uint32_t* partials, int num_windows, uint8_t out[96], int chains, int cbits = 16, int planes = 15) {
+  int bounds[65];
+  if (chains < 1) chains = 1;
+  if (chains > 64) chains = 64;
+  const int used = tail_split(cbits * num_windows, chains, bounds);
+  TeChecked chk;
+  TeH::Ext acc = teh_tail_piece(partials, bounds[used - 1], bounds[used], chk, cbits, planes);
+  for (int k = used - 2; k >= 0; k--) acc = chk.add(acc, teh_tail_piece(partials, bounds[k], bounds[k + 1], chk, cbits, planes));
+  if (chk.bad) return true;
+  teh_to_wire(acc, out);
+  return false;
+}
+
 // false: done; true: an exceptional case of the law (out untouched).
 inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96], int cbits = 16, int planes = 15) {
   TeChecked chk;

@@ -2560,34 +2560,11 @@ int convert_table(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, int form) 
 // the pieces up.  The cuts balance (hi - lo) x 17 + lo x 7 over the threads, so the pieces shrink towards the top:
 // 256 positions on 6 threads are 110 / 65 / 38 / 22 / 13 / 8 positions and ~1 900 products on the critical path,
 // against 2 496 for six equal blocks stitched by the caller and ~4 350 for one thread.
-constexpr double TAIL_STEP_COST = 17.0, TAIL_DBL_COST = 7.0;
-inline int tail_split(int positions, int chains, int* bounds) {  // bounds[0 .. used]; returns used <= chains
-  double lo = 0.0, hi = positions * TAIL_STEP_COST;
-  auto reach = [&](double t) {
-    double o = 0.0;
-    for (int k = 0; k < chains; k++) o += std::max(0.0, (t - TAIL_DBL_COST * o) / TAIL_STEP_COST);
-    return o;
-  };
-  for (int it = 0; it < 48; it++) {
-    const double t = 0.5 * (lo + hi);
-    (reach(t) >= positions ? hi : lo) = t;
-  }
-  int used = 0;
-  double o = 0.0;
-  bounds[0] = 0;
-  for (int k = 0; k < chains && bounds[used] < positions; k++) {
-    o += std::max(0.0, (hi - TAIL_DBL_COST * o) / TAIL_STEP_COST);
-    const int b = k + 1 == chains ? positions : std::min(positions, (int)(o + 0.5));
-    if (b > bounds[used]) bounds[++used] = b;
-  }
-  bounds[used] = positions;
-  return used;
-}
-
-// range(lo, hi, chain) -> sum of the positions' records x 2^(position - lo); dbl / dbl_nt / add take the chain index
-// too (the Edwards form keeps one exceptional-case record per chain).
-template <class Pt, class RangeFn, class DblFn, class DblNtFn, class AddFn>
-Pt tail_horner_mt(msm377_ctx* ctx, RangeFn range, DblFn dbl, DblNtFn dbl_nt, AddFn add, int positions) {
+// piece(lo, hi, k) -> the sum of the positions' records x 2^position (fp64_host.hpp teh_tail_piece: its own Horner chain,
+// then lo doublings); add(a, b, k) adds two pieces; k is the piece's index (the Edwards form keeps one exceptional-case
+// record per piece).  The caller runs the top piece itself and adds the others up as they finish.
+template <class Pt, class PieceFn, class AddFn>
+Pt tail_horner_mt(msm377_ctx* ctx, PieceFn piece, AddFn add, int positions) {
   constexpr int MAXC = TailPool::WORKERS + 1;
   int bounds[MAXC + 1];
   const int used = tail_split(positions, std::max(1, std::min(ctx->tail_threads, MAXC)), bounds);
@@ -2601,12 +2578,9 @@ Pt tail_horner_mt(msm377_ctx* ctx, RangeFn range, DblFn dbl, DblNtFn dbl_nt, Add
     int64_t t0, t1;
     int cpu;
   } mark[MAXC];
-  auto chain = [&part, &bounds, &mark, trace, range, dbl, dbl_nt](int k) {
+  auto chain = [&part, &bounds, &mark, trace, piece](int k) {
     if (trace) mark[k].t0 = TailPool::now_ns(), mark[k].cpu = sched_getcpu();
-    Pt acc = range(bounds[k], bounds[k + 1], k);
-    for (int i = 0; i + 1 < bounds[k]; i++) acc = dbl_nt(acc, k);
-    if (bounds[k] > 0) acc = dbl(acc, k);
-    part[k] = acc;
+    part[k] = piece(bounds[k], bounds[k + 1], k);
     if (trace) mark[k].t1 = TailPool::now_ns();
   };
   for (int k = 0; k + 1 < used; k++) pool.post(k, [&chain, k] { chain(k); });
@@ -2628,10 +2602,9 @@ Pt tail_horner_mt(msm377_ctx* ctx, RangeFn range, DblFn dbl, DblNtFn dbl_nt, Add
 // out_xy untouched) -- the caller reruns on the Weierstrass path, exactly as for the GPU-side flag.
 bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows = MSM377_NUM_WINDOWS, int cbits = 16, int planes = 15) {
   if (ctx->tail_threads <= 1 || num_windows < 8) return teh_combine(partials, num_windows, out_xy, cbits, planes);
-  TeChecked chk[TailPool::WORKERS + 1];  // one per chain
+  TeChecked chk[TailPool::WORKERS + 1];  // one per piece
   const TeH::Ext r = tail_horner_mt<TeH::Ext>(
-      ctx, [&chk, partials, cbits, planes](int lo, int hi, int k) { return teh_horner_bits(partials, lo, hi, chk[k], 0, cbits, planes); },
-      [&chk](const TeH::Ext& a, int k) { return chk[k].dbl(a); }, [&chk](const TeH::Ext& a, int k) { return chk[k].dbl_nt(a); },
+      ctx, [&chk, partials, cbits, planes](int lo, int hi, int k) { return teh_tail_piece(partials, lo, hi, chk[k], cbits, planes); },
       [&chk](const TeH::Ext& a, const TeH::Ext& b, int k) { return chk[k].add(a, b); }, cbits * num_windows);
   for (const TeChecked& c : chk)
     if (c.bad) return true;
@@ -2642,18 +2615,27 @@ bool te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int 
 void xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
   if (ctx->tail_threads <= 1) return g1h_combine(partials, MSM377_NUM_WINDOWS, out_xy);
   const G1H::XYZZ r = tail_horner_mt<G1H::XYZZ>(
-      ctx, [partials](int lo, int hi, int) { return g1h_horner_bits(partials, lo, hi); }, [](const G1H::XYZZ& a, int) { return G1H::dbl(a); },
-      [](const G1H::XYZZ& a, int) { return G1H::dbl(a); }, [](const G1H::XYZZ& a, const G1H::XYZZ& b, int) { return G1H::add(a, b); },
-      16 * MSM377_NUM_WINDOWS);
+      ctx,
+      [partials](int lo, int hi, int) {
+        G1H::XYZZ acc = g1h_horner_bits(partials, lo, hi);
+        for (int i = 0; i < lo; i++) acc = G1H::dbl(acc);
+        return acc;
+      },
+      [](const G1H::XYZZ& a, const G1H::XYZZ& b, int) { return G1H::add(a, b); }, 16 * MSM377_NUM_WINDOWS);
   g1h_to_wire(r, out_xy);
 }
 
 void ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64]) {  // Edwards-BLS12: a complete law, nothing to check
   if (ctx->tail_threads <= 1) return edh_combine(partials, out_xy);
   const EdH::Ext r = tail_horner_mt<EdH::Ext>(
-      ctx, [partials](int lo, int hi, int) { return edh_horner_bits(partials, lo, hi); }, [](const EdH::Ext& a, int) { return EdH::dbl(a); },
-      [](const EdH::Ext& a, int) { return EdH::dbl_nt(a); }, [](const EdH::Ext& a, const EdH::Ext& b, int) { return EdH::add(a, b); },
-      16 * MSM377_NUM_WINDOWS);
+      ctx,
+      [partials](int lo, int hi, int) {
+        EdH::Ext acc = edh_horner_bits(partials, lo, hi);
+        for (int i = 0; i + 1 < lo; i++) acc = EdH::dbl_nt(acc);
+        if (lo > 0) acc = EdH::dbl(acc);
+        return acc;
+      },
+      [](const EdH::Ext& a, const EdH::Ext& b, int) { return EdH::add(a, b); }, 16 * MSM377_NUM_WINDOWS);
   edh_to_wire(r, out_xy);
 }
 
@@ -3486,6 +3468,14 @@ int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count) {
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
   return g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
+}
+
+int msm377_g1_combine_partials_split(const uint8_t* partials, uint32_t pieces, uint8_t out_xy[96]) {
+  if (!partials || !out_xy || ((uintptr_t)partials & 3) || pieces < 1 || pieces > 64) return MSM377_EINVAL;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(partials);
+  for (int w = 0; w < MSM377_NUM_WINDOWS; w++)
+    if (!window_record_is_te(p + (size_t)w * 16 * 48)) return MSM377_EINVAL;  // the decomposition of the Edwards tail only
+  return teh_combine_split(p, MSM377_NUM_WINDOWS, out_xy, (int)pieces) ? MSM377_EEXCEPTIONAL : MSM377_OK;
 }
 
 int msm377_g1_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out) {

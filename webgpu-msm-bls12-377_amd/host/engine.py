@@ -90,6 +90,7 @@ def load_library():
         "msm377_g1_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_window_partials_resident": (i32, [vp, vp, vp, u64, u32, u32, vp]),
         "msm377_g1_combine_partials": (i32, [vp, vp]),
+        "msm377_g1_combine_partials_split": (i32, [vp, ctypes.c_uint32, vp]),
         "msm377_g1_combine_partials_ctx": (i32, [vp, vp, vp]),
         "msm377_ctx_get_fallback_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u32)]),
         "msm377_g1_glv_window_partials_device": (i32, [vp, vp, vp, u64, u32, u32, vp]),
@@ -136,6 +137,20 @@ def combine_partials_bytes(partials: bytes, num_windows: int = NUM_WINDOWS) -> b
     rc = lib.msm377_g1_combine_window_partials(ctypes.addressof(src), int(num_windows), ctypes.addressof(out))
     if rc:
         raise MsmError(rc, "msm377_g1_combine_window_partials")
+    return out.raw
+
+
+def combine_partials_split_bytes(partials: bytes, pieces: int) -> bytes:
+    """The combine of 16 Edwards-form window records computed as the threaded host tail computes it -- ``pieces``
+    balanced pieces of the Horner chain, added up -- on the calling thread (msm377_g1_combine_partials_split)."""
+    if len(partials) != NUM_WINDOWS * WINDOW_PARTIAL_BYTES:
+        raise ValueError("expected %d bytes of partials" % (NUM_WINDOWS * WINDOW_PARTIAL_BYTES))
+    lib = load_library()
+    src = (ctypes.c_uint32 * (len(partials) // 4)).from_buffer_copy(partials)
+    out = ctypes.create_string_buffer(96)
+    rc = lib.msm377_g1_combine_partials_split(ctypes.addressof(src), int(pieces), ctypes.addressof(out))
+    if rc:
+        raise MsmError(rc, "msm377_g1_combine_partials_split")
     return out.raw
 
 
