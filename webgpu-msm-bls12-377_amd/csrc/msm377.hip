@@ -2370,6 +2370,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     // stores -- halves their HBM traffic and was slower all the same: reduce 0.290 -> 0.310 ms at 2^20, 0.278 -> 0.296
     // at 2^16.  The first levels are VALU-bound at two waves per SIMD, the later ones cost one addition's latency
     // per launch; a thread with four serial additions only lengthens that.)
+    // More waves do not help either: k_tree_step at 3 / 4 waves per SIMD (132 VGPRs, no scratch) reduces in 0.300 /
+    // 0.32 ms against 0.298 at 2; lane quads for levels 0-4 (MSM377_COOP_THREADS up to 2^20 threads) in 0.36.
     for (uint32_t r = first_level; r < tail_from; r++) {
       const uint32_t ops = (r + 1) * (NB >> (r + 1));
       bool done = false;
