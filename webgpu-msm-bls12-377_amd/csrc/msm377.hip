@@ -1889,7 +1889,7 @@ struct msm377_ctx {
   uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
   hipEvent_t aff_up_done = nullptr;
   hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
-  int aff_down_after_sort = 1;        // MSM377_AFF_AFTER_SORT=0: k_affine_down may run beside the sort (A/B knob)
+  int aff_down_after_sort = 0;        // MSM377_AFF_AFTER_SORT=1: k_affine_down waits for the sort (see affine_convert_finish)
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
   bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
   // Below this the batched conversion does not pay: it costs ~9 more products per point than the projective record and
@@ -2151,8 +2151,11 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
   } else {
     invert_block_products(ctx, 0, nblk);
   }
-  // k_affine_down beside k_local_sort: both take about three times as long as alone (0.25 ms each instead of 0.09 /
-  // 0.15 -- they fight over the memory system), so the way down waits for the sort and then has the GPU to itself.
+  // k_affine_down beside k_local_sort: each stretches the other (they fight over the memory system), and when the way
+  // down was first built letting it wait for the sort was the faster order.  At the end of round 2 -- shorter front
+  // end, zero-copy products, polled flag -- the interleaved A/B says the opposite: 2^20 2.62 -> 2.59 ms, 2^21 5.08 ->
+  // 5.02, 2^22 10.39 -> 10.21 without the wait (two contexts each way), so the way down starts as soon as the host
+  // has inverted the block products.  MSM377_AFF_AFTER_SORT=1 restores the wait.
   if (behind_sort && ctx->aff_down_after_sort) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->sort_done, 0));
   hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out);
   HIP_TRY(ctx, hipGetLastError());
