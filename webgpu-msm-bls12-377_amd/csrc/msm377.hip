@@ -432,7 +432,9 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint32_t* __restric
 // registers and recomputed instead of stashing: 17 products per point, but most of them in tree levels with idle
 // lanes -- 0.63 ms, longer than the sort it was meant to hide under.)  Points the Edwards model cannot represent
 // (Z = 0: order 2 or 4) enter the product as 1 and raise ERR_TE_CONVERT.
-constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;  // K = 4 (twice the waves, twice the host's share) measured the same
+// K = 4 (twice the waves, twice the host's share) measured the same; workgroups of 128 / 64 threads (smaller trees, 2 / 4 times
+// the host's share) stretch the conversion stage of a 2^20 MSM from 0.47 to 0.64 / 0.69 ms.
+constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
 constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running product): 13 limbs each, 208 bytes per point
 
 __device__ __forceinline__ void put13(uint32_t* w, const Fp::El& e) {
