@@ -593,7 +593,7 @@ def test_window_sharding_on_one_gpu(engine, oracle, world):
     "knobs",
     [
         {"MSM377_NARROW_QUAD_ACC": "0"},  # narrow path with a thread per work item (k_accumulate), not a lane quad
-        {"MSM377_ZERO_COPY_OUT": "0"},  # D2H copies + event instead of the gather kernel's zero-copy stores
+        {"MSM377_ZERO_COPY_OUT": "0"},  # D2H copies + event instead of zero-copy stores and a polled sequence number
         {"MSM377_TAIL_THREADS": "1"},
         {"MSM377_TAIL_THREADS": "8", "MSM377_TAIL_SPIN_US": "0", "MSM377_TAIL_NUMA": "0"},
         {"MSM377_TAIL_THREADS": "3"},

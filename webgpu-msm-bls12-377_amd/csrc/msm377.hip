@@ -1456,6 +1456,42 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   store_coord<CV>(bucket_ptr<CV>(buckets, L, ws, x) + q * CV::COORD_WORDS, c.l);
 }
 
+// One coordinate of one of a window's 16 partial points (point 0 = B[0], point 1 + l = B[2^l]) in the HOST TAIL's format:
+// re-based from the device's Montgomery radix 2^(29 NL) to 2^(32 NW32) and written as NW32 little-endian u32 words, so
+// the host does no conversion multiplications.  Used by k_gather_partials and by k_reduce_tail's own output stage.
+template <class CV>
+__device__ __forceinline__ void pack_partial(const uint32_t* __restrict__ buckets, uint32_t L, uint32_t ws, uint32_t pt, uint32_t coord,
+                                             uint32_t* __restrict__ out, uint32_t* __restrict__ host_out) {
+  const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
+  typename CV::F::El v;
+#pragma unroll
+  for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, L, ws, x)[coord * CV::COORD_WORDS + j];
+  v = CV::F::mul(v, CV::to64());
+  uint32_t w[CV::NW32];
+  CV::F::template to_words<CV::NW32>(v, w);
+  if (pt == 0 && coord == 0) w[CV::NW32 - 1] |= CV::RECORD_TAG;  // the record names its coordinate system (values are < 2^377: the bit is free)
+  const size_t at = ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
+#pragma unroll
+  for (uint32_t j = 0; j < CV::NW32; j++) out[at + j] = w[j];
+  if (host_out) {
+#pragma unroll
+    for (uint32_t j = 0; j < CV::NW32; j++) host_out[at + j] = w[j];
+  }
+}
+// The block that finishes last (a device-memory counter) hands the call over to the host: error word, then the sequence
+// number the host is polling for (wait_zero_copy_out).  Call with every store of the block issued; all threads.
+__device__ __forceinline__ void publish_to_host(uint32_t blocks, uint32_t* host_flag, uint32_t* dev_count, const int* d_err, uint32_t seq) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(dev_count, 1u) == blocks - 1) {  // every other block's records are on their way
+    __threadfence_system();
+    __hip_atomic_store(&host_flag[1], (uint32_t)__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&host_flag[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    *dev_count = 0u;  // for the next call (stream order)
+  }
+}
+
 // The last levels of the reduction in ONE launch.  After level L - 1 every window holds L lists of M = NB >> L buckets
 // (list j, created at level j, starts at bucket NB >> (j + 1)) plus the running block [0, M).  Nothing connects the
 // lists any more: each one only has to be summed, and only the running block keeps spawning new lists (levels L..14).
@@ -1464,6 +1500,9 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
 // grid: (L + 1) workgroups per window, 15 - L barriers each.  Every level of a list halves it in place exactly as
 // k_tree_step_quad does (same bucket pairs, so the partial records come out the same).
 constexpr uint32_t TAIL_THREADS = 512;  // 128 lane quads; 2 waves per SIMD, so an addition may use 256 VGPRs
+// (An output stage of its own -- every workgroup packing the partial points it ends up owning, the last one publishing
+// to the host, no k_gather_partials launch -- was built and dropped: the pack is one more field product of latency
+// at the end of every workgroup, 0.274 -> 0.282 ms at 2^12, 0.341 -> 0.348 at 2^14, 2.60 -> 2.61 at 2^20.)
 template <class CV>
 __global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __restrict__ buckets, uint32_t L, uint32_t first, int* __restrict__ err) {
   const uint32_t NB = 1u << L;
@@ -1624,34 +1663,8 @@ __global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restri
   const uint32_t g = blockIdx.x * 64 + threadIdx.x;
   const uint32_t coord = g & 3, pt = (g >> 2) % MSM377_G1_PARTIAL_POINTS, ws = g / (4 * MSM377_G1_PARTIAL_POINTS);
   // narrow windows have fewer bit planes; the host tail never reads the unused points
-  if (g < wc * MSM377_G1_PARTIAL_POINTS * 4 && pt <= L) {
-    const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
-    typename CV::F::El v;
-#pragma unroll
-    for (uint32_t j = 0; j < CV::NL; j++) v.l[j] = bucket_ptr<CV>(buckets, L, ws, x)[coord * CV::COORD_WORDS + j];
-    v = CV::F::mul(v, CV::to64());
-    uint32_t w[CV::NW32];
-    CV::F::template to_words<CV::NW32>(v, w);
-    if (pt == 0 && coord == 0) w[CV::NW32 - 1] |= CV::RECORD_TAG;  // the record names its coordinate system (values are < 2^377: the bit is free)
-    const size_t at = ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
-#pragma unroll
-    for (uint32_t j = 0; j < CV::NW32; j++) out[at + j] = w[j];
-    if (host_out) {
-#pragma unroll
-      for (uint32_t j = 0; j < CV::NW32; j++) host_out[at + j] = w[j];
-    }
-  }
-  if (host_out) {  // a kernel argument: uniform
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(dev_count, 1u) == gridDim.x - 1) {  // every other block's records are on their way
-      __threadfence_system();
-      __hip_atomic_store(&host_flag[1], (uint32_t)__hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
-      __hip_atomic_store(&host_flag[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      *dev_count = 0u;  // for the next call (stream order)
-    }
-  }
+  if (g < wc * MSM377_G1_PARTIAL_POINTS * 4 && pt <= L) pack_partial<CV>(buckets, L, ws, pt, coord, out, host_out);
+  if (host_out) publish_to_host(gridDim.x, host_flag, dev_count, d_err, seq);  // a kernel argument: uniform
 }
 
 // Synthetic bases: P_i = [a_i]G with a_i the (i+1)-th SplitMix64(seed) output, wire format.
