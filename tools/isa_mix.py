@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix per kernel from a device ISA listing (hipcc -S --cuda-device-only).
 
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -o /tmp/msm377.s webgpu-msm-bls12-377_amd/csrc/msm377.hip
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -o /tmp/msm377.s webgpu-msm-bls12-377_amd/csrc/sequencer.hip
     python tools/isa_mix.py /tmp/msm377.s > profiles/r02_final/isa_mix.json
 
 For every kernel: static counts of VALU instructions, v_mad_u64_u32, DPP moves, ds_bpermute, s_nop; and for the

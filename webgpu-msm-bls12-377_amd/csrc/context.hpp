@@ -1,0 +1,143 @@
+// The engine context behind the opaque msm377_ctx of include/msm377.h: streams, events, device workspace (layout: DESIGN.md
+// section 3), pinned host buffers, tuning state.  Shared by sequencer.hip, host_tail.hip and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "fp64_host.hpp"
+#include "tail_pool.hpp"
+
+using msm377::SortElem;
+using msm377::WorkItem;
+using msm377::TailPool;
+using msm377::Fp64;
+using msm377::MAX_WINDOW_SLOTS;
+using msm377::NARROW_SEG;
+
+struct msm377_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;      // base conversion, overlapped with decompose + sort
+  hipEvent_t bases_ready = nullptr;
+  uint64_t cap = 0;
+  std::string err;
+  // device buffers
+  uint32_t* d_raw_points = nullptr;   // cap x 24 words (host-buffer API staging)
+  uint32_t* d_raw_scalars = nullptr;  // cap x 8 words
+  uint32_t* d_bases = nullptr;        // cap x 32 words
+  uint16_t* d_digits = nullptr;       // 16 x cap
+  uint32_t* d_range_counts = nullptr; // 16 x NRANGE x chunks: per-chunk range counts, then write offsets
+  uint32_t* d_region_base = nullptr;  // 16 x (NRANGE + 1)
+  SortElem* d_sort_temp = nullptr;    // 16 x cap partitioned (index|sign, key) pairs
+  uint32_t* d_row_ptr = nullptr;      // 16 x RP
+  uint32_t* d_val_idx = nullptr;      // 16 x cap
+  uint32_t* d_buckets = nullptr;      // 16 x 52 x NB
+  uint32_t* d_buckets_snap = nullptr; // stage capture only
+  uint32_t* d_partials = nullptr;     // 2 slots x 16 x 16 x 52 (double-buffered for batches)
+  WorkItem* d_work = nullptr;         // sorted accumulation work items (<= 16 NB + 16 cap / SEG)
+  uint32_t* d_work_meta = nullptr;    // [0..SEG] length histogram, [SEG_BINS..] cursors, then total, split-row count, overflow count
+  uint32_t* d_row_ovf_base = nullptr; // 16 x NB
+  uint32_t* d_split_rows = nullptr;   // 16 x NB
+  uint32_t* d_ovf = nullptr;          // overflow partial points, 52 words each (<= 16 cap / SEG)
+  uint32_t* d_table = nullptr;        // precomputed-window table: 16 x table_cap affine records, [2^(16 w)] P_i at record w * bases_n + i
+  uint64_t table_cap = 0;
+  uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
+  uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
+  uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
+  uint32_t* h_aff_inv = nullptr;
+  uint32_t* h_aff_flag = nullptr;     // workgroups of k_affine_up that have delivered their product
+  uint32_t *dm_aff_prod = nullptr, *dm_aff_inv = nullptr, *dm_aff_flag = nullptr;
+  uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
+  hipEvent_t aff_up_done = nullptr;
+  hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
+  int aff_down_after_sort = 0;        // MSM377_AFF_AFTER_SORT=1: k_affine_down waits for the sort (see affine_convert_finish)
+  std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
+  bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
+  // Below this the batched conversion does not pay: it costs ~9 more products per point than the projective record and
+  // saves 16, but its two kernels and the host round trip sit in front of the accumulation, which they cannot hide
+  // under the (short) sort of a small input.  Interleaved A/B, projective / affine ms per MSM (tools/ab_knobs.py):
+  // 2^15 0.69 / 0.88, 2^16 0.75 / 0.89, 2^17 0.88 / 0.97, 2^18 1.19 / 1.26, 2^19 1.76 / 1.78, 2^20 2.89 / 2.79.  MSM377_AFFINE_MIN.
+  uint64_t affine_min_points = 1ull << 20;
+  int* d_err = nullptr;               // 2 slots
+  // pinned host
+  uint32_t* h_partials = nullptr;     // 2 slots
+  int* h_err = nullptr;               // 2 slots
+  hipEvent_t done_ev[2] = {};
+  // host-buffer entry points: pinned staging + copy workers (allocated on first use)
+  uint8_t* h_stage = nullptr;  // cap x 128 bytes
+  hipStream_t copy_stream[8] = {};
+  int h2d_threads = 4;                // copy workers of the host-buffer entry points (MSM377_H2D_THREADS, 1..8)
+  // state
+  uint64_t bases_n = 0;  // resident base count (fixed-base mode)
+  uint64_t last_n = 0;
+  uint32_t last_wc = 0;
+  int last_form = -1;  // MSM377_STAGE_FORM_* of the buckets the last call left (stage read-backs)
+  bool capture = false;
+  // Zero-copy output of the full-MSM path (k_gather_partials, wait_zero_copy_out); MSM377_ZERO_COPY_OUT=0: D2H copies + event.
+  int zc_out = 1;
+  bool zc_active = false;         // the call being enqueued / waited for uses it
+  uint32_t out_seq = 0;           // sequence number of the last zero-copy call
+  uint32_t* h_out_flag = nullptr; // pinned: [0] sequence number, [1] error word
+  uint32_t* dm_out_flag = nullptr;
+  uint32_t* dm_partials = nullptr;  // device address of h_partials
+  uint32_t* d_out_count = nullptr;
+  int timing = 0;  // msm377_ctx_set_timing: 0 off, 1 every stage, 2 the accumulation kernel only
+  // First reduction level run with one addition per lane quad.  0 = automatic: the first level whose 4 lanes x additions
+  // x windows fit one wave per SIMD (65536 lanes) -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from
+  // there on, slower before), 6 for 8, 4 for the 2 windows a rank of an 8-GPU run owns.  MSM377_COOP_FROM forces it (15 = never).
+  uint32_t coop_from = 0;
+  // MSM377_COOP_THREADS: a tree level runs one lane quad per addition once that takes at most this many threads.  65536 / 131072 /
+  // 262144 make no difference on the main path (2^20: 2.74 ms each); on the narrow path 131072 moves its levels 0-2 to quads.
+  uint32_t coop_threads = 131072;
+  // MSM377_NARROW_TAIL_FROM: tail_from of the narrow-window path (2048 buckets per window).  Reduce stage at 2^12 with
+  // 7 / 5 / 4 / 3 / 2: 0.106 / 0.099 / 0.096 / 0.101 / 0.122 ms (profiles/r02_final/ab_narrow_tree.txt).
+  uint32_t narrow_tail_from = 4;
+  uint32_t narrow_seg = NARROW_SEG;  // MSM377_NARROW_SEG (>= NARROW_SEG: the buffers are sized for that)
+  uint64_t narrow_quad_items = 100000;  // MSM377_NARROW_QUAD_ITEMS: most work items k_accumulate_quad is used for
+  int narrow_quad_acc = 1;         // MSM377_NARROW_QUAD_ACC=0: the narrow-window path accumulates with a thread per work item, like the main path
+  // First level of the single-launch tail of the reduction (k_reduce_tail); MSM377_TAIL_FROM, 15 = one launch per level throughout.
+  uint32_t tail_from = 7;  // measured (tools/ab_knobs.py, 2^20): 15: 2.874 ms, 7: 2.842, 6: 2.885, 5: 2.916, 4: 3.062
+  // GLV front end of the Weierstrass path: 0 = off (default), 1 = on.  phi(P) = [lambda] P holds only for points of
+  // the prime-order subgroup, so it is an opt-in: the caller vouches for the inputs (every protocol use does).
+  // Interleaved A/B on one MI355X (tools/ab_knobs.py), Weierstrass plain vs GLV ms per MSM: 2^18 1.39 / 1.24,
+  // 2^19 2.08 / 2.00, 2^20 3.56 / 3.51, 2^22 12.56 / 12.39 (halved bucket reduction and host tail).
+  int glv_mode = 0;
+  int bases_form = 0;      // TableForm of the resident base table (fixed-base mode)
+  bool te_affine_table = true;  // MSM377_TE_AFFINE_TABLE=0: resident Edwards tables stay projective (A/B knob)
+  int g1_form = 1;         // G1 full-MSM entry points: 1 = twisted Edwards form (te377.hpp, default), 0 = Weierstrass XYZZ (MSM377_G1_FORM)
+  bool last_glv = false;
+  bool merge_full_grid = true;  // MSM377_MERGE_FULL_GRID=0: fixed 64-workgroup sweep of the split-row list (A/B knob)
+  bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
+  uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
+  hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
+  hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
+  hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
+  uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
+  uint32_t upload_chunks = 4;              // chunks of the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..8): 2: 5.07, 3: 4.89, 4-6: 4.70, 8: 4.95 ms at 2^20
+  uint32_t upload_split_pct = 30;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 10..90)
+  std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
+  bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
+  TailPool tail_pool;
+  int tail_threads = 6;               // MSM377_TAIL_THREADS: threads of the host tail (1..8, tail_horner_mt)
+  // MSM377_TAIL_SPIN_US: how long at most the tail workers poll for their job after a call has armed them (TailPool;
+  // 0 = they sleep until the job is posted).  Tail stage at 2^20, interleaved (tools/ab_knobs.py): one thread 0.140 ms,
+  // six sleeping workers 0.124, six polling ones 0.089.  (Round 2 first measured no difference: the per-thread
+  // exceptional-case flags shared a cache line then and the threads fought over it -- TeChecked is padded now.)
+  int64_t tail_spin_us = 1000;
+  bool tail_trace = false;  // MSM377_TAIL_TRACE=1
+  int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
+  uint32_t last_parts = 1;
+  double stage_ms[MSM377_NUM_STAGES] = {};
+  int last_products = 0;        // field products per bucket addition of the last accumulation launch (bench.py's int32-mad roof)
+  // Inputs of at most this many points run the narrow-window path (11-bit windows: 23 x 2048 buckets instead of
+  // 16 x 32768; MSM377_NARROW_MAX, 0 = never).  Interleaved A/B, 16-bit / narrow ms per MSM (tools/ab_knobs.py):
+  // 2^10 0.64 / 0.46, 2^13 0.67 / 0.53, 2^14 0.68 / 0.51, 2^15 0.73 / 0.60, 2^16 0.74 / 0.71 (first version); at the end of
+  // round 2: 2^16 0.605 / 0.56 (its bucket reduction 0.28 / 0.10 ms, its accumulation kernel 0.14 / 0.18), hence 2^16.
+  uint64_t narrow_max_points = 1ull << 16;
+  uint64_t fallback_count = 0;  // reruns on the Weierstrass path after an exceptional case of the Edwards law
+  uint32_t fallback_mask = 0;   // MSM377_FB_* bits of the last one
+};

@@ -1,0 +1,257 @@
+// Stage 2: per-window counting sort of the digits -> CSR rows (the reference's transpose, wgsl/cuzk/transpose_serial.wgsl:34-76;
+// model cuzk/transpose.ts:14-62).  digit_key / win_shift / key_range live in decompose.hpp.
+// Device code; included by sequencer.hip only.
+#pragma once
+#include "../curves.hpp"
+#include "decompose.hpp"
+
+namespace msm377 {
+namespace {
+
+// ---- per-window counting sort (the reference's transpose, transpose_serial.wgsl:34-76) ----
+//
+// Two-level (MSD) counting sort; every pass touches each (window, point) element once:
+//   k_range_count  block (chunk, window): LDS histogram of the chunk over 256 coarse key ranges
+//   k_range_scan   block per window: region bases per range, per-chunk write offsets
+//   k_partition    block (chunk, window): appends each element (index|sign, key) to its
+//                  range's region at LDS-ranked offsets -- contiguous runs, no global atomics
+//   k_local_sort   block (range, window): counting sort of the region's <= 129 keys in LDS;
+//                  writes its row_ptr slice and its val_idx slice, a CONTIGUOUS output owned by
+//                  one block, so the 4-byte stores combine in that XCD's L2.
+// (The first version scattered straight from the digit columns: every 4-byte store then left
+// L2 as a partial write, 8x the payload, 213 us at n = 2^20.)  Order inside a bucket is free:
+// group addition commutes (the reference's transpose is stable only because it is serial).
+
+
+// Calls f(i, biased_digit) for every i in [beg, end) of a digit column, eight digits per
+// 16-byte load where the address allows it (keeps 8x more bytes in flight per thread).
+template <class F>
+__device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ dg, uint64_t beg, uint64_t end, uint32_t tid, uint32_t nthreads, F f) {
+  uint64_t head = beg;
+  while (head < end && (((uintptr_t)(dg + head)) & 15)) head++;
+  for (uint64_t i = beg + tid; i < head; i += nthreads) f(i, (uint32_t)dg[i]);
+  const uint64_t groups = (end - head) / 8;
+  const uint4* v = reinterpret_cast<const uint4*>(dg + head);
+  for (uint64_t g = tid; g < groups; g += nthreads) {
+    const uint4 q = v[g];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      f(head + g * 8 + 2 * k, w[k] & 0xffffu);
+      f(head + g * 8 + 2 * k + 1, w[k] >> 16);
+    }
+  }
+  for (uint64_t i = head + groups * 8 + tid; i < end; i += nthreads) f(i, (uint32_t)dg[i]);
+}
+
+__global__ void __launch_bounds__(1024) k_range_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts /* [ws][r][c] */,
+                                                      uint64_t n, uint32_t chunks, uint64_t per_chunk, const uint32_t* __restrict__ key_max) {
+  __shared__ uint32_t cnt[NRANGE];
+  const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t shift = win_shift(key_max[ws]);
+  if (tid < NRANGE) cnt[tid] = 0;
+  __syncthreads();
+  const uint64_t beg = (uint64_t)c * per_chunk;
+  const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
+  for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t, uint32_t biased) {
+    uint32_t key, sign;
+    digit_key(biased, key, sign);
+    atomicAdd(&cnt[key_range(key, shift)], 1u);
+  });
+  __syncthreads();
+  if (tid < NRANGE) counts[((size_t)ws * NRANGE + tid) * chunks + c] = cnt[tid];
+}
+
+// Block per window slot, thread per range: region_base[r] = elements in smaller ranges;
+// counts[ws][r][c] becomes the write offset of chunk c inside region r (absolute).
+__global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_base, uint32_t chunks) {
+  __shared__ uint32_t part[NRANGE];
+  const uint32_t ws = blockIdx.x, r = threadIdx.x;
+  uint32_t* cr = counts + ((size_t)ws * NRANGE + r) * chunks;
+  uint32_t tot = 0;
+  for (uint32_t c = 0; c < chunks; c++) tot += cr[c];
+  part[r] = tot;
+  __syncthreads();
+  for (uint32_t off = 1; off < NRANGE; off <<= 1) {
+    const uint32_t v = r >= off ? part[r - off] : 0u;
+    __syncthreads();
+    part[r] += v;
+    __syncthreads();
+  }
+  const uint32_t base = part[r] - tot;
+  region_base[ws * (NRANGE + 1) + r] = base;
+  if (r == NRANGE - 1) region_base[ws * (NRANGE + 1) + NRANGE] = part[r];
+  uint32_t run = base;
+  for (uint32_t c = 0; c < chunks; c++) {
+    const uint32_t v = cr[c];
+    cr[c] = run;
+    run += v;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_partition(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
+                                                    SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk,
+                                                    const uint32_t* __restrict__ key_max) {
+  __shared__ uint32_t cur[NRANGE];
+  const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t shift = win_shift(key_max[ws]);
+  if (tid < NRANGE) cur[tid] = counts[((size_t)ws * NRANGE + tid) * chunks + c];
+  __syncthreads();
+  const uint64_t beg = (uint64_t)c * per_chunk;
+  const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
+  SortElem* out = temp + (size_t)ws * n;
+  for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t i, uint32_t biased) {
+    uint32_t key, sign;
+    digit_key(biased, key, sign);
+    out[atomicAdd(&cur[key_range(key, shift)], 1u)] = SortElem{(uint32_t)i | (sign << 31), key};
+  });
+}
+
+// Block (range r, window slot ws), 256 threads: the region holds exactly the elements with keys
+// in [r KRANGE, (r + 1) KRANGE) (plus key 32768 for the last range).  The region was written by
+// other CUs, so every load misses L2: a region of up to LS_CACHE elements (n / 256 = 4096 on
+// average at n = 2^20) is read ONCE, eight 8-byte loads in flight per thread, and kept in LDS for
+// the scatter pass; longer regions are streamed twice.
+constexpr uint32_t LS_CACHE = 6144;
+__global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
+                                                    uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
+                                                    const uint32_t* __restrict__ key_max) {
+  __shared__ uint32_t bins[KRANGE + 1];
+  __shared__ uint32_t part[256];
+  __shared__ SortElem cache[LS_CACHE];
+  const uint32_t r = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
+  const uint32_t shift = win_shift(key_max[ws]);
+  const uint32_t KR = KRANGE >> shift;  // keys per range in this window
+  const uint32_t lo = r * KR;
+  const bool last = shift == 0 && r == NRANGE - 1;  // only the full-width layout reaches key 32768
+  const uint32_t rbeg = region_base[ws * (NRANGE + 1) + r], rend = region_base[ws * (NRANGE + 1) + r + 1];
+  const uint32_t len = rend - rbeg;
+  const bool cached = len <= LS_CACHE;
+  const SortElem* in = temp + (size_t)ws * n + rbeg;
+  if (tid <= KRANGE) bins[tid] = 0;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
+    SortElem e[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t i = i0 + u * 256 + tid;
+      e[u].key = 0xffffffffu;
+      if (i < len) e[u] = in[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t i = i0 + u * 256 + tid;
+      if (i < len) {
+        atomicAdd(&bins[e[u].key - lo], 1u);
+        if (cached) cache[i] = e[u];
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t own = tid < KR ? bins[tid] : 0u;
+  part[tid] = own;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256; off <<= 1) {
+    const uint32_t v = tid >= off ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t* rp = row_ptr + (size_t)ws * RP + lo;
+  const uint32_t start = rbeg + part[tid] - own;
+  __syncthreads();
+  if (tid < KR) {
+    bins[tid] = start;
+    rp[tid] = start;
+  }
+  if (tid == KRANGE - 1 && last) {  // key 32768 and the end sentinel
+    bins[KRANGE] = start + own;
+    rp[KRANGE] = start + own;
+    rp[KRANGE + 1] = rend;
+  }
+  if (shift) {  // narrowed ranges cover keys below NRANGE * KR only: every row above is empty and starts at the end
+    const uint32_t covered = NRANGE * KR, total = region_base[ws * (NRANGE + 1) + NRANGE];
+    const uint32_t per_block = (RP - covered + NRANGE - 1) / NRANGE;
+    uint32_t* rp_w = row_ptr + (size_t)ws * RP;
+    for (uint32_t j = tid; j < per_block; j += 256) {
+      const uint32_t idx = covered + r * per_block + j;
+      if (idx < RP) rp_w[idx] = total;
+    }
+  }
+  __syncthreads();
+  uint32_t* vi = val_idx + (size_t)ws * n;
+  if (cached) {
+    for (uint32_t i = tid; i < len; i += 256) {
+      const SortElem e = cache[i];
+      vi[atomicAdd(&bins[e.key - lo], 1u)] = e.idx_sign;
+    }
+  } else {
+    for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
+      SortElem e[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * 256 + tid;
+        if (i < len) e[u] = in[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * 256 + tid;
+        if (i < len) vi[atomicAdd(&bins[e[u].key - lo], 1u)] = e[u].idx_sign;
+      }
+    }
+  }
+}
+
+// One workgroup per window: counting sort of the window's n <= SMALL_SORT_MAX digits by key |d| in LDS, straight to the
+// CSR form the accumulation reads (row_ptr: 2^L + 2 offsets per window over keys 0 .. 2^L; val_idx: index | sign << 31).
+__global__ void __launch_bounds__(1024) k_small_sort(const uint16_t* __restrict__ digits, uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx,
+                                                     uint32_t n, uint32_t L) {
+  __shared__ uint32_t bins[SMALL_BINS_MAX + 1];
+  __shared__ uint32_t part[1024];
+  const uint32_t ws = blockIdx.x, tid = threadIdx.x;
+  const uint32_t half = 1u << L, nbins = half + 1;
+  const uint16_t* dg = digits + (size_t)ws * n;
+  for (uint32_t b = tid; b <= nbins; b += 1024) bins[b] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const int d = (int)dg[i] - (int)half;
+    atomicAdd(&bins[d < 0 ? -d : d], 1u);
+  }
+  __syncthreads();
+  // exclusive scan over the bins: each thread owns `per` consecutive bins
+  const uint32_t per = (nbins + 1023) / 1024;
+  uint32_t local = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t b = tid * per + k;
+    if (b < nbins) local += bins[b];
+  }
+  part[tid] = local;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = tid >= off ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - local;
+  uint32_t* rp = row_ptr + (size_t)ws * (half + 2);
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t b = tid * per + k;
+    if (b < nbins) {
+      const uint32_t cnt = bins[b];
+      bins[b] = run;  // becomes the write cursor of the bin
+      rp[b] = run;
+      run += cnt;
+    }
+  }
+  if (tid == 0) rp[nbins] = n;
+  __syncthreads();
+  uint32_t* vi = val_idx + (size_t)ws * n;
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const int d = (int)dg[i] - (int)half;
+    vi[atomicAdd(&bins[d < 0 ? -d : d], 1u)] = i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+
+}  // namespace
+}  // namespace msm377
