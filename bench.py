@@ -156,6 +156,44 @@ def seeded_scalars(seed, n):
     return bytes(out)
 
 
+def fixed64_scalar_sets(torch, scalars_host, n, batch):
+    """`batch` scalar sets on the device: the seeded set rotated by b entries (distinct MSMs, no 2 GB of host bignum work)."""
+    d_one = torch.frombuffer(bytearray(scalars_host), dtype=torch.uint8).cuda().view(n, 32)
+    return torch.cat([torch.roll(d_one, shifts=b, dims=0) for b in range(batch)]).contiguous().view(-1)
+
+
+def fixed64_expected(n, batch, scalars_host):
+    """Closed form of every MSM of the fixed-base batch: P_i = [a_i]G with a_i = SplitMix64(0x377)_i and scalar set b = the
+    seeded set rotated by b, so MSM_b = [sum_i k_((i - b) mod n) a_i mod r] G -- one oracle scalar multiplication of the
+    generator each.  Checker only (bench.py after its timed region, tests/test_bench_gpu.py)."""
+    import ctypes
+    import operator
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+
+    oracle = util.load_oracle()
+    with np.errstate(over="ignore"):
+        z = np.uint64(0x377) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    a = [int(v) or 1 for v in z.tolist()]
+    ks = [int.from_bytes(scalars_host[32 * i : 32 * i + 32], "little") for i in range(n)]
+    gen = ctypes.create_string_buffer(96)
+    oracle.oracle_g1_generator(ctypes.addressof(gen))
+    out = []
+    for b in range(batch):
+        rot = ks[n - b :] + ks[: n - b] if b else ks  # torch.roll(shifts=b): element i of set b is k[(i - b) mod n]
+        total = sum(map(operator.mul, rot, a)) % R_ORDER
+        exp = ctypes.create_string_buffer(96)
+        assert oracle.oracle_g1_scalar_mul(gen.raw, total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
+        out.append(exp.raw)
+    return out
+
+
 def side_workload(args, torch, msm, n):
     """Informational lines for BASELINE.json configs[2] (Edwards) and configs[4] (64 fixed-base MSMs)."""
     eng = msm.MsmEngine(n, device=0)
@@ -182,16 +220,17 @@ def side_workload(args, torch, msm, n):
         # Default: the plain affine table.  The precomputed-window table (MSM377_BENCH_PRECOMPUTE=1) saves the reduction of
         # 15 windows and most of the host tail, but its 16 x n records (2.7 GB) no longer sit in the 256 MB Infinity Cache
         # the way the 168 MB table does, and the gathers of the accumulation kernel pay for it: 2.49 vs 2.25 ms per MSM.
-        if os.environ.get("MSM377_BENCH_PRECOMPUTE", "0") == "1":
-            eng.set_bases_precomputed_device(d_points.data_ptr(), n)  # [2^(16 w)] P_i for all windows: one reduction per MSM
-            out["table"] = "precomputed window multiples, 16 x n affine records"
+        pre = os.environ.get("MSM377_BENCH_PRECOMPUTE", "0")
+        if pre in ("1", "16", "20"):
+            bits = 20 if pre == "20" else 16
+            eng.set_precompute_window(bits)
+            eng.set_bases_precomputed_device(d_points.data_ptr(), n)  # [2^(c w)] P_i for all windows: one reduction per MSM
+            out["table"] = "precomputed window multiples, %d-bit windows: %d x n affine records" % (bits, 13 if bits == 20 else 16)
         else:
             eng.set_bases_device(d_points.data_ptr(), n)
             out["table"] = "n affine records"
         out["set_bases_ms"] = round((time.perf_counter() - t_set) * 1e3, 2)
-        # 64 scalar sets: the seeded set rotated by b entries (distinct MSMs, no 2 GB of host bignum work)
-        d_one = torch.frombuffer(bytearray(scalars_host), dtype=torch.uint8).cuda().view(n, 32)
-        d_scalars = torch.cat([torch.roll(d_one, shifts=b, dims=0) for b in range(batch)]).contiguous().view(-1)
+        d_scalars = fixed64_scalar_sets(torch, scalars_host, n, batch)
         torch.cuda.synchronize()
         step = lambda: eng.msm_fixed_base_batch_device(d_scalars.data_ptr(), n, batch)  # noqa: E731
         per_step = batch
@@ -210,34 +249,10 @@ def side_workload(args, torch, msm, n):
     ms = (time.perf_counter() - t0) * 1e3 / max(1, args.steps) / per_step
     out.update({"value": round(ms, 4), "ms_per_step": round(ms * per_step, 4), "whole_job_hbm_GBps": round(alg / (ms * 1e-3) / 1e9, 2)})
     if args.workload == "fixed64" and verify_fixed:
-        # Every one of the 64 results against a closed form (after the timed region; the oracle is the checker):
-        # P_i = [a_i]G with a_i = SplitMix64(0x377)_i and scalar set b = the seeded set rotated by b, so
-        # MSM_b = [sum_i k_((i - b) mod n) a_i mod r] G -- one oracle scalar multiplication of the generator each.
-        import ctypes
-
-        import numpy as np
-
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import util
-
-        oracle = util.load_oracle()
-        with np.errstate(over="ignore"):
-            z = np.uint64(0x377) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-            z = z ^ (z >> np.uint64(31))
-        a = [int(v) or 1 for v in z.tolist()]
-        ks = [int.from_bytes(scalars_host[32 * i : 32 * i + 32], "little") for i in range(n)]
-        gen = ctypes.create_string_buffer(96)
-        oracle.oracle_g1_generator(ctypes.addressof(gen))
-        import operator
-
+        # Every one of the 64 results against a closed form (after the timed region; the oracle is the checker).
+        exp = fixed64_expected(n, batch, scalars_host)
         for b in range(batch):
-            rot = ks[n - b :] + ks[: n - b] if b else ks  # torch.roll(shifts=b): element i of set b is k[(i - b) mod n]
-            total = sum(map(operator.mul, rot, a)) % R_ORDER
-            exp = ctypes.create_string_buffer(96)
-            assert oracle.oracle_g1_scalar_mul(gen.raw, total.to_bytes(32, "little"), 32, ctypes.addressof(exp)) == 0
-            if exp.raw != res[b]:
+            if exp[b] != res[b]:
                 raise SystemExit("PARITY FAILURE: fixed-base MSM %d of the batch differs from the closed form" % b)
         out["verified"] = "all %d results bit-exact against the closed form [sum_i k_i a_i]G (oracle scalar multiplication)" % batch
     if args.workload == "ed" and not args.no_cpu_baseline:

@@ -88,6 +88,14 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
  * window then gathers points that already carry its weight, so the sixteen bucket sets are simply added together on the
  * GPU: ONE bucket reduction, one partial record and a 16-step host tail per MSM instead of 16 and 256.  Results are
  * identical.  In the Weierstrass form (msm377_ctx_set_g1_form 0) this is msm377_g1_set_bases. */
+/* Window width of the tables the next msm377_g1_set_bases_precomputed* call builds: MSM377_WINDOW_BITS (16, default: the
+ * layout above) or MSM377_WIDE_WINDOW_BITS (20): [2^(20 w)] P_i for 13 windows (13 n affine records, 2.2 GB at n = 2^20).
+ * Because every window's points already carry its weight, all windows share ONE bucket set, so the window can widen
+ * without multiplying buckets: 13 n bucket additions per MSM instead of 16 n over 2^19 buckets -- as many as the
+ * 16 x 2^15 of the plain path -- one 19-level reduction, a 20-step host tail.  (21-bit windows are still 13 for a
+ * 253-bit scalar; 22-bit ones quadruple the buckets.)  Results are identical. */
+#define MSM377_WIDE_WINDOW_BITS 20
+int msm377_ctx_set_precompute_window(msm377_ctx* ctx, int window_bits);
 int msm377_g1_set_bases_precomputed(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
 int msm377_g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint64_t n);
 /* ... then run any number of MSMs of n scalars (host or device pointer) against it. */

@@ -489,12 +489,16 @@ def test_argument_errors(engine, golden):
     assert e.value.code == -1
 
 
-def test_fixed_base_with_precomputed_window_multiples(engine, oracle):
-    """BASELINE.json config 5 ("precomputed-point reuse"): the resident table keeps [2^(16 w)] P_i for every window, the
-    sixteen bucket sets are added on the GPU, one reduction and a 16-step tail follow.  Same results as the oracle:
-    single calls, a prefix of the bases, batches, and inputs that make the Edwards form fall back."""
+@pytest.mark.parametrize("window_bits", [16, 20])
+def test_fixed_base_with_precomputed_window_multiples(engine, oracle, window_bits):
+    """BASELINE.json config 5 ("precomputed-point reuse"): the resident table keeps [2^(c w)] P_i for every window.
+    c = 16: the sixteen bucket sets are added on the GPU, one reduction and a 16-step tail follow.  c = 20
+    (msm377_ctx_set_precompute_window): 13 windows feed ONE set of 2^19 buckets -- 13 n instead of 16 n bucket
+    additions.  Same results as the oracle: single calls, a prefix of the bases, batches, and inputs that make the
+    Edwards form fall back."""
     n = 3000
     pts, _ = seeded_inputs(oracle, n, 55)
+    engine.set_precompute_window(window_bits)
     engine.set_bases_precomputed(pts)
     for s_ in range(3):
         ks = R.encode_scalars(R.rand_scalars(700 + s_, n))
@@ -507,7 +511,10 @@ def test_fixed_base_with_precomputed_window_multiples(engine, oracle):
     # edge scalars: 0, 1, r - 1, digits at the window boundaries
     pl = R.decode_points(pts)[:8]
     full = lambda d: sum((d & 0xFFFF) << (16 * w) for w in range(15))  # noqa: E731
+    wide = lambda d: sum((d & 0xFFFFF) << (20 * w) for w in range(12))  # noqa: E731  (20-bit digits at their boundaries)
     kl = [0, 1, R.R_ORDER - 1, full(0x8000), full(0x7FFF), full(0xFFFF) % R.R_ORDER, 2, (1 << 252) + 5]
+    if window_bits == 20:
+        kl[3:6] = [wide(0x80000), wide(0x7FFFF), wide(0xFFFFF) % R.R_ORDER]
     engine.set_bases_precomputed(R.encode_points(pl))
     assert engine.msm_fixed_base(R.encode_scalars(kl)) == R.encode_result(R.msm_naive(pl, kl))
     # a point outside the prime-order subgroup somewhere in the table: conversion or a doubling flags it, the table
@@ -523,6 +530,26 @@ def test_fixed_base_with_precomputed_window_multiples(engine, oracle):
     with pytest.raises(msm.MsmError) as e:
         engine.msm_fixed_base(ks)
     assert e.value.code == -5
+    engine.set_precompute_window(16)
+    with pytest.raises(msm.MsmError) as e:
+        engine.set_precompute_window(21)  # 12 x 21 = 252 bits: still 13 windows for a 253-bit scalar, not offered
+    assert e.value.code == -1
+
+
+def test_wide_windows_on_skewed_and_larger_inputs(engine, oracle):
+    """The 20-bit-window table at a size where every sort path runs (regions longer than the LDS path holds: the top
+    window's 13-bit digits crowd into the first ranges) and with heavily repeated scalars (rows far longer than a work
+    item, merged from their overflow records)."""
+    n = 40000
+    pts, ks = seeded_inputs(oracle, n, 77)
+    engine.set_precompute_window(20)
+    engine.set_bases_precomputed(pts)
+    assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
+    few = R.rand_scalars(5, 3)
+    skew = R.encode_scalars([few[i % 3] for i in range(n)])
+    assert engine.msm_fixed_base(skew) == util.oracle_msm(oracle, pts, skew)
+    engine.set_precompute_window(16)
+    engine.set_bases(pts[:96])  # drops the table
 
 
 def test_fixed_base_batches(engine, oracle):
@@ -824,3 +851,30 @@ def test_2_22_closed_form(oracle):
         # the same problem as 8 window shards
         parts = [eng.window_partials_device(d_p.data_ptr(), d_s.data_ptr(), n, *msm.windows_for_rank(r, 8)) for r in range(8)]
         assert msm.combine_partials(b"".join(parts)) == exp.raw
+
+
+@pytest.mark.parametrize("table", ["plain", "wide"])
+def test_config5_full_batch_of_64_at_2_20(engine, table):
+    """BASELINE.json configs[4] at its exact shape: 64 fixed-base MSMs of 2^20 scalars each over one resident base set
+    (the plain affine table, and the 20-bit-window precomputed table), every result against its closed form
+    [sum_i k_i a_i]G -- P_i = [a_i]G are the bench's synthetic bases, set b is the seeded scalar set rotated by b
+    (bench.fixed64_expected: one oracle scalar multiplication of the generator per MSM)."""
+    import torch
+
+    import bench
+
+    n, batch = 1 << 20, 64
+    scalars_host = bench.seeded_scalars(0x5CA1A5, n)
+    d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
+    engine.generate_bases_device(0x377, n, d_points.data_ptr())
+    if table == "wide":
+        engine.set_precompute_window(20)
+        engine.set_bases_precomputed_device(d_points.data_ptr(), n)
+    else:
+        engine.set_bases_device(d_points.data_ptr(), n)
+    d_scalars = bench.fixed64_scalar_sets(torch, scalars_host, n, batch)
+    torch.cuda.synchronize()
+    got = engine.msm_fixed_base_batch_device(d_scalars.data_ptr(), n, batch)
+    assert got == bench.fixed64_expected(n, batch, scalars_host)
+    engine.set_precompute_window(16)
+    engine.set_bases_device(d_points.data_ptr(), 1)  # drops the 2.2 GB table

@@ -52,6 +52,7 @@ def main():
     acc = [[] for _ in engines]
     red = [[] for _ in engines]
     tail = [[] for _ in engines]
+    front = [[] for _ in engines]  # convert / decompose / sort / accumulate stage (work list + kernel + merge)
     for _ in range(args.reps):
         for i, eng in enumerate(engines):
             t0 = time.perf_counter()
@@ -64,8 +65,11 @@ def main():
             acc[i].append(eng.stage_ms()["accumulate_kernel"])
             red[i].append(eng.stage_ms()["reduce"])
             tail[i].append(eng.stage_ms()["tail"])
-    for cfg, m, a, r, t in zip(args.configs, ms, acc, red, tail):
-        print("%-48s median %.4f  min %.4f  acc_kernel %.4f  reduce %.4f  tail %.4f" % (cfg, statistics.median(m), min(m), statistics.median(a), statistics.median(r), statistics.median(t)), flush=True)
+            st = eng.stage_ms()
+            front[i].append((st["convert"], st["decompose"], st["sort"], st["accumulate"]))
+    for cfg, m, a, r, t, f in zip(args.configs, ms, acc, red, tail, front):
+        fm = [statistics.median(x[k] for x in f) for k in range(4)]
+        print("%-48s median %.4f  min %.4f  acc_kernel %.4f  reduce %.4f  tail %.4f  | convert %.3f decompose %.3f sort %.3f acc_stage %.3f" % (cfg, statistics.median(m), min(m), statistics.median(a), statistics.median(r), statistics.median(t), fm[0], fm[1], fm[2], fm[3]), flush=True)
 
 
 if __name__ == "__main__":

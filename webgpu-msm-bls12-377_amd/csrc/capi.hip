@@ -65,6 +65,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
   if (const char* e = getenv("MSM377_NARROW_MAX")) ctx->narrow_max_points = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("MSM377_PRECOMP_BITS")) ctx->precomp_bits = atoi(e) == (int)WIDE_BITS ? (int)WIDE_BITS : MSM377_WINDOW_BITS;
   if (const char* e = getenv("MSM377_AFF_AFTER_SORT")) ctx->aff_down_after_sort = atoi(e);
   if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
@@ -118,7 +119,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   const size_t aff_blocks = (size_t)affine_blocks(cap) + 1;
   dalloc((void**)&ctx->d_aff_count, 64);
   ok = ok && hipMemset(ctx->d_aff_count, 0, 64) == hipSuccess;
-  dalloc((void**)&ctx->d_aff_stash, cap * AFF_STASH_WORDS * 4);
+  dalloc((void**)&ctx->d_aff_stash, (size_t)affine_blocks(cap) * AFF_BLOCK_POINTS * AFF_STASH_WORDS * 4);  // whole workgroups: the stash is piece-major per workgroup
   dalloc((void**)&ctx->d_aff_trees, aff_blocks * 2 * AFF_THREADS * 13 * 4);
   const unsigned host_flags = hipHostMallocMapped | hipHostMallocCoherent;
   ok = ok && hipHostMalloc((void**)&ctx->h_aff_prod, aff_blocks * 48, host_flags) == hipSuccess &&
@@ -157,7 +158,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table, ctx->d_wide_digits, ctx->d_wide_counts};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
@@ -327,6 +328,12 @@ int msm377_ctx_get_fallback_info(const msm377_ctx* ctx, uint64_t* count, uint32_
   if (!ctx) return MSM377_EINVAL;
   if (count) *count = ctx->fallback_count;
   if (last_mask) *last_mask = ctx->fallback_mask;
+  return MSM377_OK;
+}
+
+int msm377_ctx_set_precompute_window(msm377_ctx* ctx, int window_bits) {
+  if (!ctx || (window_bits != MSM377_WINDOW_BITS && window_bits != MSM377_WIDE_WINDOW_BITS)) return MSM377_EINVAL;
+  ctx->precomp_bits = window_bits;
   return MSM377_OK;
 }
 

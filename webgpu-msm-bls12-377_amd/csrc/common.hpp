@@ -55,9 +55,25 @@ constexpr size_t SLOT_WORDS = (size_t)MAX_WINDOW_SLOTS * MSM377_G1_PARTIAL_POINT
 // ---- batched affine conversion (kernels/convert.hpp) ----
 // K = 4 (twice the waves, twice the host's share) measured the same; workgroups of 128 / 64 threads (smaller trees, 2 / 4 times
 // the host's share) stretch the conversion stage of a 2^20 MSM from 0.47 to 0.64 / 0.69 ms.
-constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
+#ifndef MSM377_AFF_K
+#define MSM377_AFF_K 8  // build-time A/B: tools/build_variant.sh
+#endif
+#ifndef MSM377_AFF_UNROLL
+#define MSM377_AFF_UNROLL 1
+#endif
+constexpr uint32_t AFF_THREADS = 256, AFF_K = MSM377_AFF_K, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
 constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running product): 13 limbs each, 208 bytes per point
 inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POINTS - 1) / AFF_BLOCK_POINTS); }
+
+// ---- wide windows over a precomputed table (kernels/wide.hpp) ----
+constexpr uint32_t WIDE_BITS = MSM377_WIDE_WINDOW_BITS;  // signed 20-bit digits
+constexpr uint32_t WIDE_LOG = 19;        // 2^19 buckets, one set for all windows
+constexpr uint32_t WIDE_WINDOWS = 13;    // ceil(256 / 20); windows of the table: [2^(20 w)] P_i
+constexpr uint32_t WIDE_NRANGE = 4096;   // coarse sort ranges of KRANGE = 128 keys
+constexpr uint32_t WIDE_POINTS = WIDE_LOG + 1;  // partial points of the single window record: bucket sum + 19 bit planes
+static_assert((1u << WIDE_LOG) == WIDE_NRANGE * KRANGE, "ranges of KRANGE keys cover the wide bucket set");
+static_assert((1u << WIDE_LOG) <= MSM377_NUM_WINDOWS * NB, "the wide bucket set fits the main path's bucket, row and work-list buffers");
+static_assert(WIDE_POINTS * 1 <= MAX_WINDOW_SLOTS * MSM377_G1_PARTIAL_POINTS, "the wide window record fits a partial-record slot");
 
 constexpr uint32_t G1_REC_WORDS = 32;     // a Weierstrass base record, 128 bytes (curves.hpp G1Dev::REC_WORDS)
 constexpr uint32_t GLV_WINDOWS = MSM377_GLV_WINDOWS;

@@ -45,6 +45,10 @@ struct msm377_ctx {
   uint32_t* d_ovf = nullptr;          // overflow partial points, 52 words each (<= 16 cap / SEG)
   uint32_t* d_table = nullptr;        // precomputed-window table: 16 x table_cap affine records, [2^(16 w)] P_i at record w * bases_n + i
   uint64_t table_cap = 0;
+  uint32_t table_windows = 0;         // windows the allocated table holds (16, or WIDE_WINDOWS)
+  int precomp_bits = MSM377_WINDOW_BITS;  // window width msm377_g1_set_bases_precomputed builds its next table for: 16 or 20 (msm377_ctx_set_precompute_window, MSM377_PRECOMP_BITS)
+  uint32_t* d_wide_digits = nullptr;  // wide windows: 13 x n u32 biased 20-bit digits, the flat list the sort reads
+  uint32_t* d_wide_counts = nullptr;  // wide windows: MAX_SORT_BLOCKS x 4096 per-chunk range counts, then 4096 range totals
   uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
   uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
   uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
@@ -54,6 +58,7 @@ struct msm377_ctx {
   uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
   hipEvent_t aff_up_done = nullptr;
   hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
+  uint32_t table_window_bits = MSM377_WINDOW_BITS;  // doublings between two windows of a precomputed table (AffDoublingSource)
   int aff_down_after_sort = 0;        // MSM377_AFF_AFTER_SORT=1: k_affine_down waits for the sort (see affine_convert_finish)
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
   bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)

@@ -155,19 +155,20 @@ void invert_block_products(msm377_ctx* ctx, uint32_t b0, uint32_t b1) {
   }
 }
 
-int invert_block_products_mt(msm377_ctx* ctx, uint32_t nblk) {
+int invert_block_products_mt(msm377_ctx* ctx, uint32_t b0, uint32_t b1) {
+  const uint32_t nblk = b1 > b0 ? b1 - b0 : 0;
   if (nblk >= 32 && !single_threaded(ctx)) {
     TailPool& pool = ctx->tail_pool;
     pool.start();
     const int parts = std::min(ctx->tail_threads, TailPool::WORKERS + 1);
     const uint32_t per = (nblk + parts - 1) / parts;
     for (int k = 0; k + 1 < parts; k++)
-      pool.post(k, [ctx, k, per, nblk] { invert_block_products(ctx, std::min(nblk, (uint32_t)(k + 1) * per), std::min(nblk, (uint32_t)(k + 2) * per)); });
-    invert_block_products(ctx, 0, std::min(nblk, per));
+      pool.post(k, [ctx, k, per, b0, b1] { invert_block_products(ctx, std::min(b1, b0 + (uint32_t)(k + 1) * per), std::min(b1, b0 + (uint32_t)(k + 2) * per)); });
+    invert_block_products(ctx, b0, std::min(b1, b0 + per));
     for (int k = 0; k + 1 < parts; k++)
       if (!pool.wait(k)) return worker_timeout(ctx);
   } else {
-    invert_block_products(ctx, 0, nblk);
+    invert_block_products(ctx, b0, b1);
   }
   return MSM377_OK;
 }

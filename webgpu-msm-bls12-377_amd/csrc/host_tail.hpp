@@ -18,9 +18,9 @@ int te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int n
 int xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]);
 int ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64]);  // Edwards-BLS12: a complete law, nothing to check
 
-// Inverses of the block products [0, nblk) the conversion's way up left in ctx->h_aff_prod, into ctx->h_aff_inv
+// Inverses of the block products [b0, b1) the conversion's way up left in ctx->h_aff_prod, into ctx->h_aff_inv
 // (Montgomery's trick with one Fermat inversion per thread; results re-based to the device's Montgomery radix).
-int invert_block_products_mt(msm377_ctx* ctx, uint32_t nblk);
+int invert_block_products_mt(msm377_ctx* ctx, uint32_t b0, uint32_t b1);
 // The same for blocks [b0, b1) on the calling thread.
 void invert_block_products(msm377_ctx* ctx, uint32_t b0, uint32_t b1);
 

@@ -79,13 +79,14 @@ struct AffWireSource {  // wire format (x || y, canonical Weierstrass coordinate
     return Fp::is_zero(z);
   }
 };
-struct AffDoublingSource {  // [2^16] of the point in an affine record of the previous window's table (precomputed-window tables)
+struct AffDoublingSource {  // [2^bits] of the point in an affine record of the previous window's table (precomputed-window tables)
   const uint32_t* prev;
+  uint32_t bits;  // window width of the table: 16, or 20 for the wide-window table
   __device__ __forceinline__ bool load(uint64_t i, Fp::El& n1, Fp::El& n2, Fp::El& z) const {
     Te377::Ext p = Te377::from_base_affine(TeAffBase::load_base(prev, (uint32_t)i), false);
     bool bad = false;
 #pragma unroll 1
-    for (int k = 0; k < MSM377_WINDOW_BITS; k++) {
+    for (uint32_t k = 0; k < bits; k++) {
       p = Te377::add(p, p);  // the unified law doubles
       bad |= Te377::is_bad(p);
     }
@@ -96,6 +97,10 @@ struct AffDoublingSource {  // [2^16] of the point in an affine record of the pr
   }
 };
 // Heap-shaped product tree over the workgroup's thread totals: leaves at AFF_THREADS + tid, root at 1, 13 words a node.
+// Stash layout (round 3): 16-byte piece k of point (blk, j, tid) at piece index ((blk AFF_K + j) 13 + k) AFF_THREADS + tid, so
+// that every store (and every load on the way down) of a wave is 1 KB of contiguous memory.  Round 2 kept a point's
+// 208 bytes together: each of a wave's 13 stores then touched 64 different lines, and whichever sort kernel ran beside
+// the conversion queued behind those requests (k_decompose 16 -> 107 us, k_local_sort 84 -> 224 us).
 template <class SRC>
 __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t n, uint32_t* __restrict__ stash,
                                                               uint32_t* __restrict__ trees, uint32_t* __restrict__ block_prod, uint32_t* __restrict__ host_flag, uint32_t* __restrict__ dev_count,
@@ -107,11 +112,11 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
   // the flag with a plain store.
   using K = G1Consts;
   __shared__ uint32_t tree[2 * AFF_THREADS][13];
-  const uint32_t tid = threadIdx.x;
-  const uint64_t base = (uint64_t)blockIdx.x * AFF_BLOCK_POINTS + tid;
+  const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+  const uint64_t base = (uint64_t)blk * AFF_BLOCK_POINTS + tid;
   bool bad = false;
   Fp::El c = Fp::one();
-#pragma unroll 1
+#pragma unroll MSM377_AFF_UNROLL
   for (uint32_t j = 0; j < AFF_K; j++) {
     const uint64_t i = base + (uint64_t)j * AFF_THREADS;
     if (i >= n) break;
@@ -125,9 +130,9 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
     put13(o + 13, n2);
     put13(o + 26, z);
     put13(o + 39, c);
-    uint4* dst = reinterpret_cast<uint4*>(stash + i * AFF_STASH_WORDS);
+    uint4* dst = reinterpret_cast<uint4*>(stash) + ((size_t)blk * AFF_K + j) * (AFF_STASH_WORDS / 4) * AFF_THREADS + tid;
 #pragma unroll
-    for (int k = 0; k < (int)AFF_STASH_WORDS / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    for (int k = 0; k < (int)AFF_STASH_WORDS / 4; k++) dst[(size_t)k * AFF_THREADS] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
     c = Fp::mul(c, z);
   }
   if (bad) atomicOr(err, ERR_TE_CONVERT);
@@ -137,7 +142,7 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
     if (tid < size) put13(tree[size + tid], Fp::mul(get13(tree[2 * (size + tid)]), get13(tree[2 * (size + tid) + 1])));
   }
   __syncthreads();
-  uint32_t* out = trees + (size_t)blockIdx.x * (2 * AFF_THREADS * 13);
+  uint32_t* out = trees + (size_t)blk * (2 * AFF_THREADS * 13);
   const uint32_t* flat = &tree[0][0];
   for (uint32_t k = tid; k < 2 * AFF_THREADS * 13; k += AFF_THREADS) out[k] = flat[k];
   if (tid == 0) {  // the root in the host's field format (radix 2^384), like the partial records
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
     uint32_t w[12];
     Fp::to_words<12>(root, w);
 #pragma unroll
-    for (int j = 0; j < 12; j++) block_prod[(size_t)blockIdx.x * 12 + j] = w[j];
+    for (int j = 0; j < 12; j++) block_prod[(size_t)blk * 12 + j] = w[j];
     __threadfence_system();  // the product is on its way before this workgroup counts itself
     if (atomicAdd(dev_count, 1u) == gridDim.x - 1) {
       *dev_count = 0;  // ready for the next conversion
@@ -160,15 +165,15 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
 __global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, const uint32_t* __restrict__ stash, const uint32_t* __restrict__ trees,
                                                                 const uint32_t* __restrict__ block_inv, uint32_t* __restrict__ bases) {
   __shared__ uint32_t tree[2 * AFF_THREADS][13];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t* in = trees + (size_t)blockIdx.x * (2 * AFF_THREADS * 13);
+  const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+  const uint32_t* in = trees + (size_t)blk * (2 * AFF_THREADS * 13);
   uint32_t* flat = &tree[0][0];
   for (uint32_t k = tid; k < 2 * AFF_THREADS * 13; k += AFF_THREADS) flat[k] = in[k];
   __syncthreads();
   if (tid == 0) {
     uint32_t w[12];
 #pragma unroll
-    for (int j = 0; j < 12; j++) w[j] = block_inv[(size_t)blockIdx.x * 12 + j];
+    for (int j = 0; j < 12; j++) w[j] = block_inv[(size_t)blk * 12 + j];
     put13(tree[1], Fp::from_words<12>(w));
   }
   // downwards: a node's slot turns from the product of its leaves into the inverse of that product
@@ -183,13 +188,23 @@ __global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, cons
   }
   __syncthreads();
   Fp::El inv = get13(tree[AFF_THREADS + tid]);  // 1 / (the product of this thread's Z's)
-  const uint64_t base = (uint64_t)blockIdx.x * AFF_BLOCK_POINTS + tid;
-#pragma unroll 1
+  const uint64_t base = (uint64_t)blk * AFF_BLOCK_POINTS + tid;
+#pragma unroll MSM377_AFF_UNROLL
   for (int j = (int)AFF_K - 1; j >= 0; j--) {
     const uint64_t i = base + (uint64_t)j * AFF_THREADS;
     if (i >= n) continue;
     uint32_t w[AFF_STASH_WORDS];
-    load_words16(stash + i * AFF_STASH_WORDS, w, AFF_STASH_WORDS / 4);
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(stash) + ((size_t)blk * AFF_K + j) * (AFF_STASH_WORDS / 4) * AFF_THREADS + tid;
+#pragma unroll
+      for (int k = 0; k < (int)AFF_STASH_WORDS / 4; k++) {
+        const uint4 v = src[(size_t)k * AFF_THREADS];
+        w[4 * k + 0] = v.x;
+        w[4 * k + 1] = v.y;
+        w[4 * k + 2] = v.z;
+        w[4 * k + 3] = v.w;
+      }
+    }
     const Fp::El zi = Fp::mul(inv, get13(w + 39));  // 1 / Z_j = (1 / C_j) C_(j-1)
     inv = Fp::mul(inv, get13(w + 26));              // 1 / C_(j-1)
     const Fp::El x = Fp::mul(get13(w), zi), y = Fp::mul(get13(w + 13), zi);

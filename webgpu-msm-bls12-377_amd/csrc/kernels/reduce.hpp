@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
 // the host does no conversion multiplications.  Used by k_gather_partials and by k_reduce_tail's own output stage.
 template <class CV>
 __device__ __forceinline__ void pack_partial(const uint32_t* __restrict__ buckets, uint32_t L, uint32_t ws, uint32_t pt, uint32_t coord,
-                                             uint32_t* __restrict__ out, uint32_t* __restrict__ host_out) {
+                                             uint32_t* __restrict__ out, uint32_t* __restrict__ host_out, uint32_t pp = MSM377_G1_PARTIAL_POINTS) {
   const uint32_t x = pt == 0 ? 0u : (1u << (pt - 1));
   typename CV::F::El v;
 #pragma unroll
@@ -190,7 +190,7 @@ __device__ __forceinline__ void pack_partial(const uint32_t* __restrict__ bucket
   uint32_t w[CV::NW32];
   CV::F::template to_words<CV::NW32>(v, w);
   if (pt == 0 && coord == 0) w[CV::NW32 - 1] |= CV::RECORD_TAG;  // the record names its coordinate system (values are < 2^377: the bit is free)
-  const size_t at = ((size_t)(ws * MSM377_G1_PARTIAL_POINTS + pt) * 4 + coord) * CV::NW32;
+  const size_t at = ((size_t)(ws * pp + pt) * 4 + coord) * CV::NW32;  // pp points per window record: 16, or WIDE_POINTS for the one wide window
 #pragma unroll
   for (uint32_t j = 0; j < CV::NW32; j++) out[at + j] = w[j];
   if (host_out) {
@@ -260,11 +260,11 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __res
 template <class CV>
 __global__ void __launch_bounds__(64) k_gather_partials(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, uint32_t wc, uint32_t L,
                                                       uint32_t* __restrict__ host_out = nullptr, uint32_t* host_flag = nullptr,
-                                                      uint32_t* dev_count = nullptr, const int* d_err = nullptr, uint32_t seq = 0) {
+                                                      uint32_t* dev_count = nullptr, const int* d_err = nullptr, uint32_t seq = 0, uint32_t pp = MSM377_G1_PARTIAL_POINTS) {
   const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-  const uint32_t coord = g & 3, pt = (g >> 2) % MSM377_G1_PARTIAL_POINTS, ws = g / (4 * MSM377_G1_PARTIAL_POINTS);
+  const uint32_t coord = g & 3, pt = (g >> 2) % pp, ws = g / (4 * pp);
   // narrow windows have fewer bit planes; the host tail never reads the unused points
-  if (g < wc * MSM377_G1_PARTIAL_POINTS * 4 && pt <= L) pack_partial<CV>(buckets, L, ws, pt, coord, out, host_out);
+  if (g < wc * pp * 4 && pt <= L) pack_partial<CV>(buckets, L, ws, pt, coord, out, host_out, pp);
   if (host_out) publish_to_host(gridDim.x, host_flag, dev_count, d_err, seq);  // a kernel argument: uniform
 }
 

@@ -13,9 +13,9 @@ namespace {
 // Two-level (MSD) counting sort; every pass touches each (window, point) element once:
 //   k_range_count  block (chunk, window): LDS histogram of the chunk over 256 coarse key ranges
 //   k_range_scan   block per window: region bases per range, per-chunk write offsets
-//   k_partition    block (chunk, window): appends each element (index|sign, key) to its
-//                  range's region at LDS-ranked offsets -- contiguous runs, no global atomics
-//   k_local_sort   block (range, window): counting sort of the region's <= 129 keys in LDS;
+//   k_partition_staged  block (chunk, window): appends each element (index|sign, key) to its
+//                  range's region at LDS-ranked offsets, a tile at a time -- contiguous runs, no global atomics
+//   k_local_sort_lds  block (range, window): counting sort of the region's <= 129 keys in LDS;
 //                  writes its row_ptr slice and its val_idx slice, a CONTIGUOUS output owned by
 //                  one block, so the 4-byte stores combine in that XCD's L2.
 // (The first version scattered straight from the digit columns: every 4-byte store then left
@@ -89,62 +89,155 @@ __global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ co
   }
 }
 
-__global__ void __launch_bounds__(1024) k_partition(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
-                                                    SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk,
-                                                    const uint32_t* __restrict__ key_max) {
-  __shared__ uint32_t cur[NRANGE];
+// The partition pass, its scatter staged through LDS (round 3).  Round 2's k_partition appended every element straight to
+// one of 256 write streams per workgroup, 8 bytes at a time; a stream advances by 2 KB over the workgroup's whole life,
+// so its lines left L2 half-written: WRITE_SIZE 184 MB for 131 MB of sort_temp, 87 us.  Here a workgroup takes its
+// chunk in tiles of PT_TILE elements: ranks inside the tile from an LDS histogram (the one atomic per element that is
+// left), an exclusive scan over the 256 ranges, the elements parked in LDS in range order, and then the tile is written
+// out by consecutive lanes -- a range's ~32 elements of the tile are one contiguous run of its stream, so whole lines go
+// out in one piece and only the two ends of a run are partial.  Interleaved A/B at 2^20: sort stage 0.344 -> 0.314 ms.
+constexpr uint32_t PT_TILE = 8192;  // 8 digits (one 16-byte load) per thread; 64 KB of staging: two workgroups per CU
+__global__ void __launch_bounds__(1024) k_partition_staged(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
+                                                           SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk,
+                                                           const uint32_t* __restrict__ key_max) {
+  __shared__ uint32_t cur[NRANGE];     // this workgroup's write cursor in every range's region
+  __shared__ uint32_t cnt[NRANGE];     // elements of the tile per range
+  __shared__ uint32_t toff[NRANGE];    // first slot of the range in the staged tile
+  __shared__ uint32_t gdelta[NRANGE];  // region position of a staged element = its slot + gdelta[range]
+  __shared__ uint32_t wsum[NRANGE / 64];
+  __shared__ SortElem stage[PT_TILE];
   const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
   const uint32_t shift = win_shift(key_max[ws]);
-  if (tid < NRANGE) cur[tid] = counts[((size_t)ws * NRANGE + tid) * chunks + c];
+  if (tid < NRANGE) {
+    cur[tid] = counts[((size_t)ws * NRANGE + tid) * chunks + c];
+    cnt[tid] = 0;
+  }
   __syncthreads();
   const uint64_t beg = (uint64_t)c * per_chunk;
   const uint64_t end = (beg + per_chunk < n) ? beg + per_chunk : n;
+  const uint16_t* dg = digits + (size_t)ws * n;
   SortElem* out = temp + (size_t)ws * n;
-  for_each_digit(digits + (size_t)ws * n, beg, end, tid, 1024, [&](uint64_t i, uint32_t biased) {
-    uint32_t key, sign;
-    digit_key(biased, key, sign);
-    out[atomicAdd(&cur[key_range(key, shift)], 1u)] = SortElem{(uint32_t)i | (sign << 31), key};
-  });
+  for (uint64_t tile0 = beg; tile0 < end; tile0 += PT_TILE) {
+    const uint64_t i0 = tile0 + (uint64_t)tid * 8;
+    uint32_t d[8];
+    uint32_t valid = 0;  // bit j: digit j exists
+    if (i0 + 8 <= end && (((uintptr_t)(dg + i0)) & 15) == 0) {
+      const uint4 q = *reinterpret_cast<const uint4*>(dg + i0);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        d[2 * k] = w[k] & 0xffffu;
+        d[2 * k + 1] = w[k] >> 16;
+      }
+      valid = 0xffu;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        d[j] = 0;
+        if (i0 + j < end) {
+          d[j] = dg[i0 + j];
+          valid |= 1u << j;
+        }
+      }
+    }
+    uint32_t key[8], sign[8], rg[8], rk[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      digit_key(d[j], key[j], sign[j]);
+      rg[j] = key_range(key[j], shift);
+      rk[j] = 0;
+      if ((valid >> j) & 1u) rk[j] = atomicAdd(&cnt[rg[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt over the 256 ranges: wave scans + the four wave totals
+    uint32_t mine = 0, incl = 0;
+    if (tid < NRANGE) {
+      mine = cnt[tid];
+      incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up((int)incl, off, 64);
+        if ((tid & 63) >= (uint32_t)off) incl += v;
+      }
+      if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < NRANGE) {
+      uint32_t before = 0;
+      for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
+      const uint32_t excl = before + incl - mine;
+      toff[tid] = excl;
+      gdelta[tid] = cur[tid] - excl;
+      cur[tid] += mine;
+      cnt[tid] = 0;  // for the next tile (its atomics come after this tile's last barrier)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((valid >> j) & 1u) stage[toff[rg[j]] + rk[j]] = SortElem{(uint32_t)(i0 + j) | (sign[j] << 31), key[j]};
+    __syncthreads();
+    const uint32_t tile_len = (uint32_t)((end - tile0 < PT_TILE) ? end - tile0 : PT_TILE);
+    for (uint32_t p = tid; p < tile_len; p += 1024) {
+      const SortElem e = stage[p];
+      out[gdelta[key_range(e.key, shift)] + p] = e;
+    }
+    __syncthreads();
+  }
 }
 
-// Block (range r, window slot ws), 256 threads: the region holds exactly the elements with keys
-// in [r KRANGE, (r + 1) KRANGE) (plus key 32768 for the last range).  The region was written by
-// other CUs, so every load misses L2: a region of up to LS_CACHE elements (n / 256 = 4096 on
-// average at n = 2^20) is read ONCE, eight 8-byte loads in flight per thread, and kept in LDS for
-// the scatter pass; longer regions are streamed twice.
-constexpr uint32_t LS_CACHE = 6144;
-__global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
-                                                    uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
-                                                    const uint32_t* __restrict__ key_max) {
+// Block (range r, window slot ws), 256 threads: the region holds exactly the elements with keys in [r KRANGE, (r + 1) KRANGE)
+// (plus key NBK for the last range).  It was written by other CUs, so every load misses L2: a region of up to LS_CACHE
+// elements is read ONCE into REGISTERS (24 per thread, all their loads in flight at once), histogrammed, scattered into a
+// 24 KB LDS array in key order and written to val_idx by consecutive lanes -- whole lines instead of 4-byte stores at
+// random places of the slice, and 25 KB of LDS per workgroup (round 2 kept the region in 48 KB of LDS and scattered
+// straight to val_idx: three workgroups per CU and no room for the base conversion that runs beside the sort; interleaved
+// A/B at 2^20: sort stage 0.344 -> 0.296 ms, whole MSM 2.60 -> 2.55).  Longer regions (skewed scalars) are streamed twice.
+constexpr uint32_t LS_CACHE = 6144;           // region length (n / 256 = 4096 on average at n = 2^20) the register / LDS path holds
+constexpr uint32_t LS_REG = LS_CACHE / 256;  // elements per thread
+__global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
+                                                        uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
+                                                        const uint32_t* __restrict__ key_max, uint32_t NR, uint32_t NBK) {
+  // NR ranges per window over keys 0 .. NBK (256 x 2^15 on the main path; 4096 x 2^19, one window, no key_max, for the
+  // wide windows of kernels/wide.hpp); the last range also owns key NBK.
+  const uint32_t RPW = NBK + 2;  // row_ptr entries per window
   __shared__ uint32_t bins[KRANGE + 1];
   __shared__ uint32_t part[256];
-  __shared__ SortElem cache[LS_CACHE];
+  __shared__ uint32_t sorted[LS_CACHE];
   const uint32_t r = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
-  const uint32_t shift = win_shift(key_max[ws]);
+  const uint32_t shift = key_max ? win_shift(key_max[ws]) : 0u;
   const uint32_t KR = KRANGE >> shift;  // keys per range in this window
   const uint32_t lo = r * KR;
-  const bool last = shift == 0 && r == NRANGE - 1;  // only the full-width layout reaches key 32768
-  const uint32_t rbeg = region_base[ws * (NRANGE + 1) + r], rend = region_base[ws * (NRANGE + 1) + r + 1];
+  const bool last = shift == 0 && r == NR - 1;  // only the full-width layout reaches key NBK
+  const uint32_t rbeg = region_base[ws * (NR + 1) + r], rend = region_base[ws * (NR + 1) + r + 1];
   const uint32_t len = rend - rbeg;
   const bool cached = len <= LS_CACHE;
   const SortElem* in = temp + (size_t)ws * n + rbeg;
   if (tid <= KRANGE) bins[tid] = 0;
   __syncthreads();
-  for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
-    SortElem e[8];
+  SortElem e[LS_REG];
+  if (cached) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t i = i0 + u * 256 + tid;
-      e[u].key = 0xffffffffu;
+    for (uint32_t u = 0; u < LS_REG; u++) {
+      const uint32_t i = u * 256 + tid;
+      e[u].key = lo;
+      e[u].idx_sign = 0;
       if (i < len) e[u] = in[i];
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t i = i0 + u * 256 + tid;
-      if (i < len) {
-        atomicAdd(&bins[e[u].key - lo], 1u);
-        if (cached) cache[i] = e[u];
+    for (uint32_t u = 0; u < LS_REG; u++)
+      if (u * 256 + tid < len) atomicAdd(&bins[e[u].key - lo], 1u);
+  } else {
+    for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
+      SortElem f[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * 256 + tid;
+        f[u].key = lo;
+        if (i < len) f[u] = in[i];
       }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + u * 256 + tid < len) atomicAdd(&bins[f[u].key - lo], 1u);
     }
   }
   __syncthreads();
@@ -157,7 +250,7 @@ __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t* rp = row_ptr + (size_t)ws * RP + lo;
+  uint32_t* rp = row_ptr + (size_t)ws * RPW + lo;
   const uint32_t start = rbeg + part[tid] - own;
   __syncthreads();
   if (tid < KR) {
@@ -169,34 +262,35 @@ __global__ void __launch_bounds__(256) k_local_sort(const SortElem* __restrict__
     rp[KRANGE] = start + own;
     rp[KRANGE + 1] = rend;
   }
-  if (shift) {  // narrowed ranges cover keys below NRANGE * KR only: every row above is empty and starts at the end
-    const uint32_t covered = NRANGE * KR, total = region_base[ws * (NRANGE + 1) + NRANGE];
-    const uint32_t per_block = (RP - covered + NRANGE - 1) / NRANGE;
-    uint32_t* rp_w = row_ptr + (size_t)ws * RP;
+  if (shift) {  // narrowed ranges cover keys below NR * KR only: every row above is empty and starts at the end
+    const uint32_t covered = NR * KR, total = region_base[ws * (NR + 1) + NR];
+    const uint32_t per_block = (RPW - covered + NR - 1) / NR;
+    uint32_t* rp_w = row_ptr + (size_t)ws * RPW;
     for (uint32_t j = tid; j < per_block; j += 256) {
       const uint32_t idx = covered + r * per_block + j;
-      if (idx < RP) rp_w[idx] = total;
+      if (idx < RPW) rp_w[idx] = total;
     }
   }
   __syncthreads();
   uint32_t* vi = val_idx + (size_t)ws * n;
   if (cached) {
-    for (uint32_t i = tid; i < len; i += 256) {
-      const SortElem e = cache[i];
-      vi[atomicAdd(&bins[e.key - lo], 1u)] = e.idx_sign;
-    }
+#pragma unroll
+    for (uint32_t u = 0; u < LS_REG; u++)
+      if (u * 256 + tid < len) sorted[atomicAdd(&bins[e[u].key - lo], 1u) - rbeg] = e[u].idx_sign;
+    __syncthreads();
+    for (uint32_t i = tid; i < len; i += 256) vi[rbeg + i] = sorted[i];
   } else {
     for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
-      SortElem e[8];
+      SortElem f[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t i = i0 + u * 256 + tid;
-        if (i < len) e[u] = in[i];
+        if (i < len) f[u] = in[i];
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t i = i0 + u * 256 + tid;
-        if (i < len) vi[atomicAdd(&bins[e[u].key - lo], 1u)] = e[u].idx_sign;
+        if (i < len) vi[atomicAdd(&bins[f[u].key - lo], 1u)] = f[u].idx_sign;
       }
     }
   }

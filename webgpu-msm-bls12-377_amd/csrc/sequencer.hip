@@ -41,6 +41,7 @@
 #include "kernels/generate.hpp"
 #include "kernels/reduce.hpp"
 #include "kernels/sort.hpp"
+#include "kernels/wide.hpp"
 
 namespace msm377 {
 namespace eng {
@@ -151,6 +152,10 @@ int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, uint64_t f
 }
 
 // Phase 1, queued on the side stream: products up to one value per workgroup, delivered into pinned host memory.
+// (Round 3 tried the conversion as TWO launches per direction, blocks [0, h) and [h, nblk), so that the host inverts the
+// first half's products while the second half is still on its way up and the ~50 us round trip idles nothing: slower,
+// 2.60 -> 2.72 ms at 2^20.  The conversion is latency-bound at two workgroups per CU -- a half-size launch is one
+// workgroup per CU and takes 104 us where the full one takes 171 -- so the chain grew from 171 + 50 + 170 to 4 x ~110 us.)
 int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, const uint32_t* prev_window_records = nullptr, bool clear_err = true) {
   if (n == 0) return MSM377_OK;
   const uint32_t nblk = affine_blocks(n);
@@ -158,8 +163,8 @@ int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, con
   __atomic_store_n(ctx->h_aff_flag, 0u, __ATOMIC_RELEASE);
   if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   if (prev_window_records)
-    hipLaunchKernelGGL(k_affine_up<AffDoublingSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffDoublingSource{prev_window_records}, n, ctx->d_aff_stash,
-                       ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
+    hipLaunchKernelGGL(k_affine_up<AffDoublingSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffDoublingSource{prev_window_records, ctx->table_window_bits}, n,
+                       ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
   else
     hipLaunchKernelGGL(k_affine_up<AffWireSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffWireSource{d_raw}, n, ctx->d_aff_stash, ctx->d_aff_trees,
                        ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
@@ -188,7 +193,7 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
     return MSM377_EHIP;
   }
   {
-    const int inv_rc = invert_block_products_mt(ctx, nblk);
+    const int inv_rc = invert_block_products_mt(ctx, 0, nblk);
     if (inv_rc) return inv_rc;
   }
   // k_affine_down beside k_local_sort: each stretches the other (they fight over the memory system), and when the way
@@ -244,6 +249,9 @@ struct Phase {
   // L = cbits - 1 as a run-time argument.
   uint32_t cbits = MSM377_WINDOW_BITS;
   uint32_t bucket_log = MSM377_WINDOW_BITS - 1;  // L: 2^L buckets per window (NARROW_LOG on the small-input path)
+  // Wide windows over a precomputed table (kernels/wide.hpp): `table` holds [2^(20 w)] P_i for 13 windows, the call has
+  // ONE window slot of 2^19 buckets fed by the flat list of 13 n digits (cbits = WIDE_BITS, bucket_log = WIDE_LOG).
+  bool wide = false;
 };
 
 struct PartView {
@@ -258,12 +266,14 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   hipStream_t st = pv.st;
   const uint32_t wc = pv.wc, part = pv.part;
   const uint32_t L = ph.bucket_log, NB = 1u << L, RP = NB + 2;  // this call's bucket geometry (shadows the main path's constants)
-  const bool narrow = ph.cbits != MSM377_WINDOW_BITS;
+  const bool wide = ph.wide;
+  const bool narrow = !wide && ph.cbits != MSM377_WINDOW_BITS;
+  const uint64_t entries = wide ? (uint64_t)WIDE_WINDOWS * n : (uint64_t)wc * n;  // (window, point) pairs of this part
   static_assert((uint64_t)NARROW_WINDOWS * SMALL_SORT_MAX / NARROW_SEG + NARROW_WINDOWS * (1u << NARROW_LOG) <= (uint64_t)MSM377_NUM_WINDOWS * 32768, "narrow work items fit the work-item buffer");
   // per launch: each part must fill the GPU on its own.  Narrow windows: a small input is all latency -- a work item is
   // a serial chain of ~10 us additions -- so its chains are cut at 8 entries (the buffers, sized for 16 windows of
   // 2^15 rows plus entries / SEG_MIN items, hold the 23 x 2^11 rows and 23 n / 8 items of an input this small easily).
-  const uint32_t SEG = (narrow && !ctx->seg_plain) ? ctx->narrow_seg : auto_seg(ctx, (uint64_t)wc * n, glv);
+  const uint32_t SEG = (narrow && !ctx->seg_plain) ? ctx->narrow_seg : auto_seg(ctx, entries, glv);
   uint16_t* digits = ctx->d_digits + (size_t)pv.ws0 * n;
   uint32_t* range_counts = ctx->d_range_counts + (size_t)part * NRANGE * (MAX_SORT_BLOCKS / 2);
   uint32_t* region_base = ctx->d_region_base + (size_t)pv.ws0 * (NRANGE + 1);
@@ -283,7 +293,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // then measures window 15 of the plain front end.
   hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, meta_block, META_BLOCK_WORDS, (uint32_t*)d_err, (ph.clear_err && part == 0) ? 1u : 0u);
   uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
-  const uint64_t max_items = (uint64_t)wc * NB + (uint64_t)wc * n / SEG;  // every row has an item; extra ones are full segments
+  const uint64_t max_items = (uint64_t)wc * NB + entries / SEG;  // every row has an item; extra ones are full segments
   // a lane quad per work item while the launch is one chain's latency (up to 2^14 points: ~94 k items); beyond that
   // the quads are VALU-bound like threads and only add their exchange instructions (kernel at 2^16: 0.216 / 0.183 ms)
   const bool quad_acc = std::is_same<BP, CV>::value && std::is_same<CV, TeDev>::value && narrow && ctx->narrow_quad_acc && !ph.table && max_items <= ctx->narrow_quad_items;
@@ -293,7 +303,9 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // only within each window: the accumulation kernel went from 0.038 to 0.054 ms at 2^12.)
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
-    if (narrow)
+    if (wide)
+      hipLaunchKernelGGL(k_decompose_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_wide_digits, n, d_err);
+    else if (narrow)
       hipLaunchKernelGGL(k_decompose_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, ph.cbits, L, wc, d_err);
     else if (glv)
       hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n_scalars, pv.wb, wc, d_err);
@@ -302,7 +314,24 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
   }
 
-  if (narrow) {
+  if (wide) {  // one counting sort of the 13 n entries by key: 4096 ranges, then k_local_sort_lds per range
+    StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
+    const uint64_t N = entries;
+    uint32_t chunks = MAX_SORT_BLOCKS;
+    const uint64_t want = (N + 8191) / 8192;
+    if (chunks > want) chunks = (uint32_t)(want ? want : 1);
+    const uint64_t per_chunk = ((N + chunks - 1) / chunks + 3) & ~3ull;  // whole 16-byte groups of digits
+    uint32_t* counts = ctx->d_wide_counts;
+    uint32_t* tot = counts + (size_t)MAX_SORT_BLOCKS * WIDE_NRANGE;
+    hipLaunchKernelGGL(k_wide_count, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, N, per_chunk);
+    hipLaunchKernelGGL(k_wide_total, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, tot, chunks);
+    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, tot, region_base);
+    hipLaunchKernelGGL(k_wide_offsets, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, region_base, chunks);
+    hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk);
+    hipLaunchKernelGGL(k_local_sort_lds, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB);
+    HIP_TRY(ctx, hipGetLastError());
+    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
+  } else if (narrow) {
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
     hipLaunchKernelGGL(k_small_sort, dim3(wc), dim3(1024), 0, st, digits, row_ptr, val_idx, (uint32_t)n, L);
     HIP_TRY(ctx, hipGetLastError());
@@ -317,9 +346,9 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, range_counts, region_base, chunks);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_partition, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk, key_max);
+    hipLaunchKernelGGL(k_partition_staged, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk, key_max);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_local_sort, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max);
+    hipLaunchKernelGGL(k_local_sort_lds, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB);
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   }
@@ -406,7 +435,9 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       }
     // Levels [0, coop_from): one thread per addition (VALU-bound: 2^18 additions per level at first); [coop_from,
     // tail_from): one lane quad per addition, one launch per level; [tail_from, levels): k_reduce_tail, one launch.
-    const uint32_t tail_from = CV::HAS_QUAD ? std::min(narrow ? ctx->narrow_tail_from : ctx->tail_from, levels) : levels;
+    // (wide windows: 2^19 buckets in one window -- the lists of the single-launch tail must be down to one round of
+    // 128 lane quads, which is level L - 8)
+    const uint32_t tail_from = CV::HAS_QUAD ? std::min(wide ? levels - 8 : narrow ? ctx->narrow_tail_from : ctx->tail_from, levels) : levels;
     // (Fusing pairs of thread-level levels -- four buckets a quarter-list apart per thread, four additions, three
     // stores -- halves their HBM traffic and was slower all the same: reduce 0.290 -> 0.310 ms at 2^20, 0.278 -> 0.296
     // at 2^16.  The first levels are VALU-bound at two waves per SIMD, the later ones cost one addition's latency
@@ -431,12 +462,14 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
         HIP_TRY(ctx, hipGetLastError());
       }
     }
+    const uint32_t pp = wide ? WIDE_POINTS : (uint32_t)MSM377_G1_PARTIAL_POINTS;  // points per window record
     if (ctx->zc_active)  // set by enqueue_windows for this call: one part, slot 0
-      hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets, d_partials, wc, L, ctx->dm_partials,
-                         ctx->dm_out_flag, ctx->d_out_count, (const int*)d_err, ctx->out_seq);
+      hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * pp * 4 + 63) / 64), dim3(64), 0, st, buckets, d_partials, wc, L, ctx->dm_partials,
+                         ctx->dm_out_flag, ctx->d_out_count, (const int*)d_err, ctx->out_seq, pp);
     else
-      hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * MSM377_G1_PARTIAL_POINTS * 4 + 63) / 64), dim3(64), 0, st, buckets,
-                         d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc, L);
+      hipLaunchKernelGGL(k_gather_partials<CV>, dim3((wc * pp * 4 + 63) / 64), dim3(64), 0, st, buckets,
+                         d_partials + (size_t)pv.ws0 * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS, wc, L, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                         (const int*)nullptr, 0u, pp);
     HIP_TRY(ctx, hipGetLastError());
   }
   return MSM377_OK;
@@ -487,8 +520,9 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->part_join, 0));
   }
   const uint32_t wc_out = ph.table ? 1u : wc;  // precomputed-window tables fold the windows on the GPU
+  const uint32_t pp_out = ph.wide ? WIDE_POINTS : (uint32_t)MSM377_G1_PARTIAL_POINTS;
   if (!ctx->zc_active) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc_out * MSM377_G1_PARTIAL_POINTS * CV::OUT_WORDS * 4,
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partials + (size_t)slot * SLOT_WORDS, d_partials, (size_t)wc_out * pp_out * CV::OUT_WORDS * 4,
                                  hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_err + slot, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   }
@@ -640,12 +674,20 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
     // Small inputs: narrow windows (k_decompose_narrow); the window-indexed buffers are sized for them too
     // (msm377_ctx_create: wcap).  Stage read-backs describe the 16-bit geometry.
     bool narrow = form != TABLE_TE_PRECOMP && n <= ctx->narrow_max_points && n <= SMALL_SORT_MAX && !ctx->capture;
+    const bool wide = form == TABLE_TE_PRECOMP && ctx->table_window_bits == WIDE_BITS;
     for (;;) {
       uint32_t windows = MSM377_NUM_WINDOWS;
       int cbits = MSM377_WINDOW_BITS, planes = MSM377_WINDOW_BITS - 1;
       ph.cbits = MSM377_WINDOW_BITS;
       ph.bucket_log = MSM377_WINDOW_BITS - 1;
-      if (narrow) {
+      if (wide) {  // one window slot of 2^19 buckets over the 13-window table
+        ph.wide = true;
+        ph.cbits = WIDE_BITS;
+        ph.bucket_log = WIDE_LOG;
+        windows = 1;
+        cbits = WIDE_BITS;
+        planes = WIDE_LOG;
+      } else if (narrow) {
         ph.cbits = NARROW_BITS;
         ph.bucket_log = NARROW_LOG;
         windows = NARROW_WINDOWS;
@@ -674,7 +716,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
-      const int tr = form == TABLE_TE_PRECOMP ? (teh_combine(ctx->h_partials, 1, out_xy) ? TAIL_EXCEPTIONAL : TAIL_OK)
+      const int tr = form == TABLE_TE_PRECOMP ? (teh_combine(ctx->h_partials, 1, out_xy, cbits, planes) ? TAIL_EXCEPTIONAL : TAIL_OK)
                                               : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes);
       time_tail(ctx, t0);
       if (tr < 0) return tr;
@@ -952,6 +994,17 @@ int ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d
   return MSM377_OK;
 }
 
+// The precomputed-window table and its wide-window work buffers (allocated on demand, 2.2-2.7 GB at 2^20 points).
+void free_table(msm377_ctx* ctx) {
+  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts})
+    if (p) (void)hipFree(p);
+  ctx->d_table = nullptr;
+  ctx->d_wide_digits = nullptr;
+  ctx->d_wide_counts = nullptr;
+  ctx->table_cap = 0;
+  ctx->table_windows = 0;
+}
+
 int g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
@@ -964,6 +1017,10 @@ int g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
   if (form_is_te(form) && d_points != ctx->d_raw_points)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw_points, d_points, n * 96, hipMemcpyDeviceToDevice, ctx->stream2));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+  if (ctx->d_table) {  // a plain table replaces a precomputed one: give its gigabytes back
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_table(ctx);
+  }
   ctx->bases_n = n;
   ctx->bases_form = form;
   return MSM377_OK;
@@ -978,25 +1035,37 @@ int g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n) {
 }
 
 // Precomputed-window tables (BASELINE.json config 5 "precomputed-point reuse"; the reference lists precomputation as
-// future work, README.md:558-563): T[w][i] = [2^(16 w)] P_i for the 16 windows, as affine Edwards records.  Window 0
-// is the batched conversion of the input; every further window doubles the previous one 16 times (unified law) and
-// runs through the same batched inversion (k_affine_up<AffDoublingSource> -> host -> k_affine_down).
+// future work, README.md:558-563): T[w][i] = [2^(c w)] P_i as affine Edwards records.  Window 0 is the batched
+// conversion of the input; every further window doubles the previous one c times (unified law) and runs through the
+// same batched inversion (k_affine_up<AffDoublingSource> -> host -> k_affine_down).
+//   c = 16 (round 2): 16 windows, the main path's geometry; the 16 bucket sets are folded after the accumulation.
+//   c = 20 (round 3, msm377_ctx_set_precompute_window): 13 windows over ONE set of 2^19 buckets -- 13 n bucket
+//          additions per MSM instead of 16 n (kernels/wide.hpp).
 int g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
   int rc = check_args(ctx, d_points, d_points, n, true);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->g1_form != 1 || n == 0) return g1_set_bases_device(ctx, d_points, n);  // Weierstrass form: no precomputation
-  if (ctx->table_cap < n) {
-    if (ctx->d_table) (void)hipFree(ctx->d_table);
-    ctx->d_table = nullptr;
-    ctx->table_cap = 0;
-    if (hipMalloc((void**)&ctx->d_table, (size_t)MSM377_NUM_WINDOWS * n * TeAffBase::REC_WORDS * 4) != hipSuccess) {
+  const bool wide = ctx->precomp_bits == (int)WIDE_BITS;
+  const uint32_t windows = wide ? WIDE_WINDOWS : (uint32_t)MSM377_NUM_WINDOWS;
+  if (ctx->table_cap < n || ctx->table_windows != windows) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight reads the old table
+    free_table(ctx);
+    bool ok = hipMalloc((void**)&ctx->d_table, (size_t)windows * n * TeAffBase::REC_WORDS * 4) == hipSuccess;
+    if (ok && wide)
+      ok = hipMalloc((void**)&ctx->d_wide_digits, (size_t)WIDE_WINDOWS * n * 4) == hipSuccess &&
+           hipMalloc((void**)&ctx->d_wide_counts, ((size_t)MAX_SORT_BLOCKS + 1) * WIDE_NRANGE * 4) == hipSuccess;
+    if (!ok) {
+      free_table(ctx);
+      (void)hipGetLastError();
       ctx->err = "precomputed-window table: out of device memory";
       return MSM377_ENOMEM;
     }
     ctx->table_cap = n;
+    ctx->table_windows = windows;
   }
-  for (uint32_t w = 0; w < MSM377_NUM_WINDOWS && rc == MSM377_OK; w++) {
+  ctx->table_window_bits = wide ? WIDE_BITS : (uint32_t)MSM377_WINDOW_BITS;
+  for (uint32_t w = 0; w < windows && rc == MSM377_OK; w++) {
     uint32_t* mine = ctx->d_table + (size_t)w * n * TeAffBase::REC_WORDS;
     rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n, w == 0 ? nullptr : mine - (size_t)n * TeAffBase::REC_WORDS, w == 0);
     if (rc == MSM377_OK) rc = affine_convert_finish(ctx, mine, n);
@@ -1057,12 +1126,19 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
   const uint32_t* sc = (const uint32_t*)d_scalars;
   const int form = resident_form(ctx, n);
   const bool glv = form == TABLE_XYZZ_GLV, te = form_is_te(form);
-  const uint32_t W = glv ? GLV_WINDOWS : MSM377_NUM_WINDOWS;
+  const bool wide = form == TABLE_TE_PRECOMP && ctx->table_window_bits == WIDE_BITS;
+  const uint32_t W = wide ? 1u : glv ? GLV_WINDOWS : (uint32_t)MSM377_NUM_WINDOWS;  // window slots of a call
   Phase table_phase;
   if (form == TABLE_TE_PRECOMP) {
     table_phase.table = ctx->d_table;
     table_phase.table_stride = ctx->bases_n;
   }
+  if (wide) {
+    table_phase.wide = true;
+    table_phase.cbits = WIDE_BITS;
+    table_phase.bucket_log = WIDE_LOG;
+  }
+  const int tail_cbits = wide ? (int)WIDE_BITS : 16, tail_planes = wide ? (int)WIDE_LOG : 15;
   const int W_tail = form == TABLE_TE_PRECOMP ? 1 : (int)W;  // window records the host combines per MSM
   std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
   bool te_fallback = false;
@@ -1093,7 +1169,7 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
         return rc;
       }
       if (te) {
-        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W_tail, out_xy + (size_t)96 * (b - 1))) {
+        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W_tail, out_xy + (size_t)96 * (b - 1), tail_cbits, tail_planes)) {
           te_fallback = true;
           note_fallback(ctx, MSM377_FB_TAIL);
         }

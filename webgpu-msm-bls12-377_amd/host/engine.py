@@ -108,6 +108,7 @@ def load_library():
         "msm377_ctx_set_timing": (i32, [vp, i32]),
         "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
         "msm377_ctx_get_products_per_addition": (i32, [vp]),
+        "msm377_ctx_set_precompute_window": (i32, [vp, i32]),
         "msm377_ctx_get_stage_form": (i32, [vp]),
         "msm377_ctx_set_narrow_max": (i32, [vp, u64]),
     }
@@ -246,6 +247,11 @@ class MsmEngine:
         if len(points) % 96:
             raise ValueError("points buffer length must be a multiple of 96")
         self._check(self._lib.msm377_g1_set_bases_precomputed(self._ctx, bytes(points), len(points) // 96), "msm377_g1_set_bases_precomputed")
+
+    def set_precompute_window(self, window_bits: int):
+        """Window width of the next precomputed table: 16 (16 windows) or 20 (13 windows over one set of 2^19 buckets,
+        msm377_ctx_set_precompute_window)."""
+        self._check(self._lib.msm377_ctx_set_precompute_window(self._ctx, int(window_bits)), "msm377_ctx_set_precompute_window")
 
     def set_bases_precomputed_device(self, d_points: int, n: int):
         self._check(self._lib.msm377_g1_set_bases_precomputed_device(self._ctx, d_points, int(n)), "msm377_g1_set_bases_precomputed_device")
