@@ -303,7 +303,7 @@ def main():
     import torch
 
     import webgpu_msm_bls12_377_amd as msm
-    from webgpu_msm_bls12_377_amd.host.sharding import ShardedMsm, windows_for_rank
+    from webgpu_msm_bls12_377_amd.host.sharding import ShardedMsm, choose_partition, points_for_rank, windows_for_rank
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -363,15 +363,31 @@ def main():
     # selects the Weierstrass XYZZ path behind the GLV front end
     te_single = world == 1 and os.environ.get("MSM377_G1_FORM", "1") != "0"
     glv_single = world == 1 and not te_single and os.environ.get("MSM377_GLV", "0") == "1"
+    # How the MSM is split over the ranks: "points" (every rank a complete MSM of its n / G points, one all-gather of
+    # 96-byte results) or "windows" (BASELINE.json config 4's window subtasks: one all-gather of window records, host
+    # combine).  Default from the measured per-rank times (host/sharding.py choose_partition);
+    # MSM377_BENCH_PARTITION forces one.
+    partition = os.environ.get("MSM377_BENCH_PARTITION") or choose_partition(n, world)
+    if partition not in ("points", "windows") or use_glv:
+        partition = "windows"
     sharder = ShardedMsm(rank, world, device=xdev, force_collective=force_sharded)
     sharder_glv = ShardedMsm(rank, world, device=xdev, num_windows=8) if use_glv else None
     resident = (world > 1 or force_sharded) and backend == "nccl" and not use_glv  # records stay in HBM until the all-gather
 
+    def rerun_weierstrass(b, c, out_ptr):  # Edwards records that add up to an exceptional case: this rank's windows again in form 0
+        eng.set_g1_form("weierstrass")
+        try:
+            eng.window_partials_resident(pp, sp, n, b, c, out_ptr)
+        finally:
+            eng.set_g1_form("edwards")
+
     def step():
         if world == 1 and not force_sharded:
             return eng.msm_device(pp, sp, n)
+        if partition == "points":
+            return sharder.run_points(lambda first, count: eng.msm_device(pp + 96 * first, sp + 32 * first, count), n)
         if resident:
-            return sharder.run_resident(lambda b, c, out_ptr: eng.window_partials_resident(pp, sp, n, b, c, out_ptr), eng.combine_partials)
+            return sharder.run_resident(lambda b, c, out_ptr: eng.window_partials_resident(pp, sp, n, b, c, out_ptr), eng.combine_partials, rerun_weierstrass)
         if use_glv:
             try:
                 return sharder_glv.run(lambda b, c: eng.glv_window_partials_device(pp, sp, n, b, c))
@@ -436,20 +452,28 @@ def main():
         whole_bytes, acc_bytes = algorithmic_bytes(n, glv_path)
         nwin = 8 if (world > 1 and use_glv) else NUM_WINDOWS
         _, my_windows = windows_for_rank(rank, world, nwin)
+        sharded = world > 1 or force_sharded
+        if sharded and partition == "points":  # this rank's launch: all windows over its slice of the points
+            my_windows = nwin
+            share = points_for_rank(rank, world, n)[1] / n
+            _, acc_slice = algorithmic_bytes(points_for_rank(rank, world, n)[1], glv_path)
+        else:
+            share = my_windows / nwin
+            acc_slice = acc_bytes * share
         acc_ms = stages.get("accumulate_kernel", 0.0)  # HIP events around the k_accumulate launch alone
-        acc_bytes_launch = acc_bytes * my_windows / nwin  # one launch covers this rank's share of the windows
+        acc_bytes_launch = acc_slice  # one launch covers this rank's share of the windows (or of the points)
         achieved = acc_bytes_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic, traffic_source = pmc_traffic_bytes(args.log_n) if world == 1 else (None, None)
         # int32-mad roof: one launch adds every non-zero digit's point once (16 n additions less the 2^-16 share of
         # zero digits: negligible, not subtracted) at `products` field products of 337 multiply-adds each
         products = eng.accumulate_products()
-        lane_mads = NUM_WINDOWS * n * my_windows / nwin * products * MADS_PER_FIELD_PRODUCT
+        lane_mads = NUM_WINDOWS * n * share * products * MADS_PER_FIELD_PRODUCT
         mad_rate = lane_mads / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         # all VALU issue slots of the loop, each class at its own measured rate: the roof the kernel actually sits under
         isa_tag, valu_per_add, mads_per_add = isa_loop_mix(products)
         issue_frac = None
         if valu_per_add and acc_ms > 0:
-            adds = NUM_WINDOWS * n * my_windows / nwin
+            adds = NUM_WINDOWS * n * share
             issue_ms = adds * (mads_per_add / MAD_PEAK_GLANEOPS + (valu_per_add - mads_per_add) / ALU_PEAK_GLANEOPS) / 1e9 * 1e3
             issue_frac = round(issue_ms / acc_ms, 4)
         out = {
@@ -472,7 +496,8 @@ def main():
                 "points": "P_i=[a_i]G, a_i=SplitMix64(0x377)",
                 "scalars": "uniform < r, SplitMix64(0x5ca1a5)",
                 "setup_msms": setup_msms,  # untimed MSMs run as part of setup, before the warm-up steps (clock ramp after idle)
-                "parallelism": ("%s windows sharded over %d GPUs, one RCCL all-gather" % ("8 GLV" if use_glv else "16", world)) if (world > 1 or force_sharded) else "single GPU",
+                "parallelism": (("points sharded over %d GPUs (a complete MSM of n / %d points per rank), one RCCL all-gather of 96-byte results" % (world, world))
+                                if partition == "points" else "%s windows sharded over %d GPUs, one RCCL all-gather" % ("8 GLV" if use_glv else "16", world)) if sharded else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -535,6 +560,12 @@ def main():
                 "kind": "port",
                 "sample": "the full 2^%d workload, 1 run, same inputs; result bit-exact with the GPU's" % args.log_n,
             }
+        if world > 1 and not args.no_cpu_baseline:
+            # multi-rank parity, after the timed region: the closed form [sum_i k_i a_i]G of the synthetic inputs (one oracle
+            # scalar multiplication of the generator; the oracle is the checker)
+            if fixed64_expected(n, 1, scalars_host)[0] != result:
+                raise SystemExit("PARITY FAILURE: the %d-rank result differs from the closed form at n=2^%d" % (world, args.log_n))
+            out["verified"] = "bit-exact against the closed form [sum_i k_i a_i]G (oracle scalar multiplication)"
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:

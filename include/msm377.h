@@ -136,6 +136,15 @@ int msm377_g1_combine_partials_split(const uint8_t* partials, uint32_t pieces, u
 /* The same on the context's tail threads (four Horner chains, as inside msm377_g1_msm): 0.12 instead of 0.18 ms. */
 int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uint8_t out_xy[96]);
 
+/* Point sharding, the other partitioning of a multi-GPU run (SURVEY.md section 8e names it as the fallback): rank g runs a
+ * COMPLETE MSM -- msm377_g1_msm_device, all 16 windows, its own host tail -- over its slice [g n / G, (g + 1) n / G) of the
+ * points and scalars, the ranks all-gather their 96-byte results and every rank adds them up with this function: the
+ * sum of `count` affine wire points (the identity as the wire format writes it, x = 0 and y = 1, is accepted).  Nothing
+ * is replicated (conversion, decomposition, sort, reduction and tail all shrink with n / G), so it scales further than
+ * window sharding, which replicates the base conversion and whose per-window fixed costs stay.  Host-only, no context.
+ * MSM377_EINVAL for a coordinate that is not below p. */
+int msm377_g1_add_points(const uint8_t* points_xy, uint32_t count, uint8_t out_xy[96]);
+
 /* The same sharding behind the GLV front end (opt-in, prime-order subgroup points only -- see
  * msm377_ctx_set_glv; Weierstrass form): MSM377_GLV_WINDOWS = 8 windows over {P_i, phi(P_i)};
  * win_begin / win_count index those 8.  Returns MSM377_EGLVRANGE when a scalar does not split into

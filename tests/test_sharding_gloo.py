@@ -59,19 +59,52 @@ def _worker(rank, world, port, case_name, q):
 
         out4 = sh.run_resident(write_records)
 
-        # with a combine callback (MsmEngine.combine_partials on the GPU box): uniform window counts hand it the address of
-        # the gathered buffer itself, ragged ones the re-packed bytes
+        # with a combine callback (MsmEngine.combine_partials on the GPU box): it gets the 16 records re-packed without the
+        # per-rank status words
         seen = []
 
         def combine(parts):
             seen.append(type(parts).__name__)
-            if isinstance(parts, int):
-                parts = ctypes.string_at(parts, 16 * 3072)
             return msm.combine_partials(parts)
 
         out5 = sh.run_resident(write_records, combine)
-        ok_kind = seen == (["int"] if 16 % world == 0 else ["bytes"])
-        q.put((rank, out == case["expected"] and out2 == out and out3 == out and out4 == out and out5 == out and ok_kind))
+        ok_kind = seen == ["bytes"]
+
+        # POINT sharding: every rank a complete MSM of its slice (the oracle stands in for MsmEngine.msm_device), one
+        # all-gather of 96-byte results, msm377_g1_add_points on every rank
+        n = len(case["scalars"]) // 32
+        from webgpu_msm_bls12_377_amd.host.sharding import points_for_rank
+
+        slices = [points_for_rank(r, world, n) for r in range(world)]
+        covered = sum(c for _, c in slices) == n and all(slices[r][0] + slices[r][1] == slices[r + 1][0] for r in range(world - 1))
+
+        def msm_fn(first, count):
+            return util.oracle_msm(oracle, case["points"][96 * first : 96 * (first + count)], case["scalars"][32 * first : 32 * (first + count)])
+
+        out6 = sh.run_points(msm_fn, n)
+
+        # a rank whose local work fails still enters the collective, and then EVERY rank raises (no rank is left waiting
+        # for the collective's timeout)
+        def failing(first, count):
+            if rank == world - 1:
+                raise msm.MsmError(-2, "injected")
+            return msm_fn(first, count)
+
+        def failing_records(begin, count, d_out):
+            if rank == 0:
+                raise msm.MsmError(-4, "injected")
+            write_records(begin, count, d_out)
+
+        agreed = True
+        for call in (lambda: sh.run_points(failing, n), lambda: sh.run_resident(failing_records), lambda: sh.run(lambda b, c: failing(0, 0) and partials_fn(b, c))):
+            try:
+                call()
+                agreed = False
+            except msm.MsmError as e:
+                agreed = agreed and e.code in (-2, -4)
+        out7 = sh.run_points(msm_fn, n)  # and the exchange buffers are still usable afterwards
+        q.put((rank, out == case["expected"] and out2 == out and out3 == out and out4 == out and out5 == out and ok_kind and covered and out6 == out
+               and agreed and out7 == out))
     finally:
         dist.destroy_process_group()
 

@@ -65,6 +65,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
   if (const char* e = getenv("MSM377_NARROW_MAX")) ctx->narrow_max_points = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("MSM377_TABLE_PREFETCH")) ctx->table_prefetch = atoi(e);
   if (const char* e = getenv("MSM377_PRECOMP_BITS")) ctx->precomp_bits = atoi(e) == (int)WIDE_BITS ? (int)WIDE_BITS : MSM377_WINDOW_BITS;
   if (const char* e = getenv("MSM377_AFF_AFTER_SORT")) ctx->aff_down_after_sort = atoi(e);
   if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
@@ -230,10 +231,9 @@ int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uin
     all_w = all_w && !te;
   }
   int rc = MSM377_OK;
-  struct Disarm {
-    msm377_ctx* c;
-    ~Disarm() { c->tail_pool.disarm(); }
-  } disarm{ctx};
+  // (The workers are not pre-woken for this call: between a rank's window_partials call and this combine lie the
+  // all-gather and a D2H copy, longer than any spin deadline -- round 2 armed them from window_partials and they spun
+  // for nothing, on every rank of the host.)
   if (all_te)
     {
     const int tr = eng::te_tail(ctx, rec, out_xy);
@@ -256,6 +256,11 @@ int msm377_g1_fold_window_partials(uint8_t* partials, uint32_t win_count) {
 int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]) {
   if (!partials || !out_xy || ((uintptr_t)partials & 3)) return MSM377_EINVAL;
   return g1_combine_tagged(reinterpret_cast<const uint32_t*>(partials), MSM377_NUM_WINDOWS, out_xy) ? MSM377_EEXCEPTIONAL : MSM377_OK;
+}
+
+int msm377_g1_add_points(const uint8_t* points_xy, uint32_t count, uint8_t out_xy[96]) {
+  if (!out_xy || (count && !points_xy)) return MSM377_EINVAL;
+  return g1h_add_wire_points(points_xy, count, out_xy) ? MSM377_OK : MSM377_EINVAL;
 }
 
 int msm377_g1_combine_partials_split(const uint8_t* partials, uint32_t pieces, uint8_t out_xy[96]) {

@@ -47,6 +47,7 @@ struct msm377_ctx {
   uint64_t table_cap = 0;
   uint32_t table_windows = 0;         // windows the allocated table holds (16, or WIDE_WINDOWS)
   int precomp_bits = MSM377_WINDOW_BITS;  // window width msm377_g1_set_bases_precomputed builds its next table for: 16 or 20 (msm377_ctx_set_precompute_window, MSM377_PRECOMP_BITS)
+  int table_prefetch = 1;             // MSM377_TABLE_PREFETCH=0: precomputed tables gather with the main path's prefetch depth (k_accumulate PF = 0)
   uint32_t* d_wide_digits = nullptr;  // wide windows: 13 x n u32 biased 20-bit digits, the flat list the sort reads
   uint32_t* d_wide_counts = nullptr;  // wide windows: MAX_SORT_BLOCKS x 4096 per-chunk range counts, then 4096 range totals
   uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)

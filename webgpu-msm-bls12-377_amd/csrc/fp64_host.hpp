@@ -580,6 +580,31 @@ inline bool g1_combine_tagged(const uint32_t* partials, int num_windows, uint8_t
   return false;
 }
 
+// Sum of `count` affine wire points (x || y, 48-byte little-endian each; the identity as the wire format writes it:
+// x = 0, y = 1) -- the last step of a points-partitioned multi-GPU MSM, whose ranks each return the MSM of their own
+// slice of the points (host/sharding.py).  false: a coordinate is not below p.
+inline bool g1h_add_wire_points(const uint8_t* pts, uint32_t count, uint8_t out[96]) {
+  G1H::XYZZ acc = G1H::identity();
+  for (uint32_t i = 0; i < count; i++) {
+    uint32_t w[24];
+    memcpy(w, pts + (size_t)96 * i, 96);
+    uint64_t lim[2][6];
+    for (int c = 0; c < 2; c++)
+      for (int k = 0; k < 6; k++) lim[c][k] = (uint64_t)w[12 * c + 2 * k] | ((uint64_t)w[12 * c + 2 * k + 1] << 32);
+    if (Fp64::geq_p(lim[0]) || Fp64::geq_p(lim[1])) return false;
+    bool x_zero = true, y_one = lim[1][0] == 1;
+    for (int k = 0; k < 6; k++) x_zero = x_zero && lim[0][k] == 0;
+    for (int k = 1; k < 6; k++) y_one = y_one && lim[1][k] == 0;
+    if (x_zero && y_one) continue;  // the identity
+    G1H::Affine q;
+    q.x = Fp64::mul(Fp64::from_words32(w), Fp64::from_const(G1Consts64::R2));
+    q.y = Fp64::mul(Fp64::from_words32(w + 12), Fp64::from_const(G1Consts64::R2));
+    acc = G1H::madd(acc, q);
+  }
+  g1h_to_wire(acc, out);
+  return true;
+}
+
 // ---- Edwards tail ----
 struct EdK64 {
   static Fq64::El two_d() { return Fq64::from_const(EdConsts64::ED_2D); }

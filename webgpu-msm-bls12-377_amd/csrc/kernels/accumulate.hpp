@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restric
 }
 
 // One thread per work item.  OCC = waves per SIMD the register allocator must allow.
-template <class CV, int OCC, class BP = CV>  // BP: where the input points come from (CV itself, or TeAffBase)
+template <class CV, int OCC, class BP = CV, int PF = 0>  // BP: where the input points come from (CV itself, or TeAffBase); PF: extra records in flight
 __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ val_idx,
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
@@ -146,14 +146,20 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
   const bool start_fresh = !(into && it.seg == 0);
   bool bad = false;  // an exceptional pair of the twisted Edwards law (te377.hpp): sticky, the caller falls back
   if (k < end) {
-    // Software pipeline: the index of entry k+2 and the record of entry k+1 are in flight while
-    // entry k is added, so neither the val_idx -> bases address dependency nor the gather
-    // latency stalls the wave.
-    uint32_t e_cur = vi[k];
-    uint32_t e_nxt = (k + 1 < end) ? vi[k + 1] : 0u;
-    typename BP::Base cur = BP::load_base(bases, e_cur & 0x7fffffffu);
-    bool more = true;  // cur / e_cur hold an entry that has not been added yet
-    // One stage: start the gathers for the next two entries, add entry `cur`, rotate.  FIRST is a compile-time
+    // Software pipeline: while entry k is added the record of entry k+PF+1 is on its way (its gather is issued at the
+    // start of the stage), the records of entries k+1 .. k+PF have been requested one to PF additions ago, and the index
+    // of entry k+PF+2 is being read -- so neither the val_idx -> bases address dependency nor the gather latency stalls
+    // the wave.  PF = 0 on the main path (one addition, ~10 us, covers a gather from the 168 MB table, which lives in
+    // the Infinity Cache across the 16 windows' passes); PF = 1 is for the gigabyte tables of precomputed window
+    // multiples, whose gathers come from HBM (+40 VGPRs).
+    typename BP::Base rec[PF + 1];  // rec[0]: the entry being added
+    uint32_t e[PF + 2];             // e[j]: entry of rec[j]; e[PF + 1]: the next index, already loaded
+#pragma unroll
+    for (int j = 0; j <= PF + 1; j++) e[j] = (k + j < end) ? vi[k + j] : 0u;
+#pragma unroll
+    for (int j = 0; j <= PF; j++) rec[j] = BP::load_base(bases, e[j] & 0x7fffffffu);  // (past the end: record 0, never used)
+    bool more = true;  // rec[0] / e[0] hold an entry that has not been added yet
+    // One stage: start the gathers for the entries further down, add entry rec[0], rotate.  FIRST is a compile-time
     // switch so that the chain's first entry (BP::first: a copy, one product) is PEELED off the loop -- written as
     // `start_fresh ? first(cur) : madd(acc, cur)` inside the loop the compiler evaluated both sides every
     // iteration and selected: 8 products per iteration instead of 7 (9 instead of 8 with projective records; 2697
@@ -162,20 +168,23 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
       constexpr bool FIRST = decltype(first_tag)::value;
       k++;
       more = k < end;
-      typename BP::Base nxt = cur;
-      uint32_t e_nn = 0u;
-      if (more) {
-        nxt = BP::load_base(bases, e_nxt & 0x7fffffffu);
-        if (k + 1 < end) e_nn = vi[k + 1];
+      typename BP::Base fresh = rec[PF];
+      uint32_t e_new = 0u;
+      if (k + PF < end) {
+        fresh = BP::load_base(bases, e[PF + 1] & 0x7fffffffu);
+        if (k + PF + 1 < end) e_new = vi[k + PF + 1];
       }
       if constexpr (FIRST)
-        acc = BP::first(cur, (e_cur >> 31) != 0);
+        acc = BP::first(rec[0], (e[0] >> 31) != 0);
       else
-        acc = BP::madd(acc, cur, (e_cur >> 31) != 0);
+        acc = BP::madd(acc, rec[0], (e[0] >> 31) != 0);
       bad |= CV::is_bad(acc);
-      cur = nxt;
-      e_cur = e_nxt;
-      e_nxt = e_nn;
+#pragma unroll
+      for (int j = 0; j < PF; j++) rec[j] = rec[j + 1];
+      rec[PF] = fresh;
+#pragma unroll
+      for (int j = 0; j <= PF; j++) e[j] = e[j + 1];
+      e[PF + 1] = e_new;
     };
     if (start_fresh) stage(std::true_type{});  // a chain that starts from the identity: its first entry needs no addition
     while (more) stage(std::false_type{});

@@ -5,8 +5,8 @@
 // over 2^19 buckets, exactly as many as the 16 x 2^15 of the main path.  (21 bits would still be 13 windows for a
 // 253-bit scalar -- 12 x 21 = 252 -- and 22 bits quadruple the buckets.)
 //
-// The 13 digit columns form ONE flat list of N = 13 n entries whose position w n + i IS the table record to gather,
-// so the sort is a single counting sort of N entries by key |d| in 0 .. 2^19: 4096 coarse ranges of 128 keys (the
+// The 13 digit columns form ONE flat list of N = 13 n entries; position w n + i names the table record w * stride + i to
+// gather, so the sort is a single counting sort of N entries by key |d| in 0 .. 2^19: 4096 coarse ranges of 128 keys (the
 // second level is the main path's k_local_sort_lds, one workgroup per range), chunk-major counters so that the scan
 // over 4096 x chunks counters is three small coalesced kernels.
 // Device code; included by sequencer.hip only.
@@ -128,9 +128,11 @@ __global__ void __launch_bounds__(256) k_wide_offsets(uint32_t* __restrict__ cou
   }
 }
 
-// Workgroup per chunk: appends each entry (position | sign << 31, key) to its range's region.
+// Workgroup per chunk: appends each entry (table record | sign << 31, key) to its range's region.  Position w n + i of
+// the digit list is window w of scalar i; the record to gather is w * stride + i (stride = points in the resident
+// table, >= n: a call may use a prefix of the bases).
 __global__ void __launch_bounds__(1024) k_wide_partition(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ counts, SortElem* __restrict__ temp, uint64_t N,
-                                                         uint64_t per_chunk) {
+                                                         uint64_t per_chunk, uint32_t n, uint32_t stride) {
   __shared__ uint32_t cur[WIDE_NRANGE];
   const uint32_t c = blockIdx.x, tid = threadIdx.x;
   for (uint32_t r = tid; r < WIDE_NRANGE; r += 1024) cur[r] = counts[(size_t)c * WIDE_NRANGE + r];
@@ -140,7 +142,8 @@ __global__ void __launch_bounds__(1024) k_wide_partition(const uint32_t* __restr
   for_each_digit32(digits, beg, end, tid, 1024, [&](uint64_t i, uint32_t biased) {
     uint32_t key, sign;
     wide_key(biased, key, sign);
-    temp[atomicAdd(&cur[wide_range(key)], 1u)] = SortElem{(uint32_t)i | (sign << 31), key};
+    const uint32_t w = (uint32_t)i / n;
+    temp[atomicAdd(&cur[wide_range(key)], 1u)] = SortElem{((uint32_t)i + w * (stride - n)) | (sign << 31), key};
   });
 }
 

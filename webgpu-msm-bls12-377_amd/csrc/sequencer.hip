@@ -327,7 +327,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     hipLaunchKernelGGL(k_wide_total, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, tot, chunks);
     hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, tot, region_base);
     hipLaunchKernelGGL(k_wide_offsets, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, region_base, chunks);
-    hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk);
+    hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk, (uint32_t)n, (uint32_t)ph.table_stride);
     hipLaunchKernelGGL(k_local_sort_lds, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB);
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
@@ -390,8 +390,14 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       }
       if (launched) {
       } else if constexpr (!std::is_same<BP, CV>::value)
-        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
+      {
+        if (ph.table && ctx->table_prefetch)  // gigabyte table: gathers come from HBM, one more record in flight
+          hipLaunchKernelGGL((k_accumulate<CV, 2, BP, 1>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                             ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
+        else
+          hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                             ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
+      }
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
                            ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
@@ -1213,7 +1219,6 @@ int window_partials(msm377_ctx* ctx, const void* d_points, const void* d_scalars
   }
   const size_t bytes = (size_t)win_count * MSM377_G1_WINDOW_PARTIAL_BYTES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->tail_threads > 1) ctx->tail_pool.prewake(ctx->tail_spin_us, std::min(ctx->tail_threads, TailPool::WORKERS + 1) - 1);  // the combine of the gathered records follows (msm377_g1_combine_partials_ctx disarms)
   if (n == 0) {  // identity partials: ZZ = 0 everywhere
     if (host_out) memset(host_out, 0, bytes);
     if (dev_out) HIP_TRY(ctx, hipMemset(dev_out, 0, bytes));
@@ -1232,9 +1237,21 @@ int window_partials(msm377_ctx* ctx, const void* d_points, const void* d_scalars
     return MSM377_OK;
   };
   if (ctx->g1_form == 1) {  // twisted Edwards form; k_gather_partials tags the records (fp64_host.hpp TE_RECORD_TAG)
-    rc = convert_bases<TeDev>(ctx, (const uint32_t*)d_points, n);
-    if (rc) return rc;
-    rc = enqueue_windows<TeDev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count, 0);
+    // Affine base records (7-product additions, batched inversion) once a point takes part in enough additions to pay for
+    // its ~9 extra conversion products: windows x points >= 2^24 -- e.g. the 8 windows a rank of a 2-GPU run owns at 2^21
+    // points and more, the 2 of an 8-GPU run at 2^23 (msm377_g1_msm_device: 16 windows, n >= 2^20).
+    const bool affine = ctx->te_affine_msm && n >= (1ull << 18) && (uint64_t)win_count * n >= (1ull << 24);
+    if (affine) {
+      rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n);
+      if (rc) return rc;
+      ctx->before_accumulate = [ctx, n]() -> int { return affine_convert_finish(ctx, ctx->d_bases, n, true); };
+      rc = enqueue_windows<TeDev, TeAffBase>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count, 0);
+      ctx->before_accumulate = nullptr;
+    } else {
+      rc = convert_bases<TeDev>(ctx, (const uint32_t*)d_points, n);
+      if (rc) return rc;
+      rc = enqueue_windows<TeDev>(ctx, (const uint32_t*)d_scalars, n, win_begin, win_count, 0);
+    }
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     if ((ctx->h_err[0] & ERR_TE_ANY) == 0) {

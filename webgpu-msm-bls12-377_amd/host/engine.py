@@ -109,6 +109,7 @@ def load_library():
         "msm377_ctx_get_stage_ms": (i32, [vp, vp]),
         "msm377_ctx_get_products_per_addition": (i32, [vp]),
         "msm377_ctx_set_precompute_window": (i32, [vp, i32]),
+        "msm377_g1_add_points": (i32, [vp, u32, vp]),
         "msm377_ctx_get_stage_form": (i32, [vp]),
         "msm377_ctx_set_narrow_max": (i32, [vp, u64]),
     }
@@ -138,6 +139,19 @@ def combine_partials_bytes(partials: bytes, num_windows: int = NUM_WINDOWS) -> b
     rc = lib.msm377_g1_combine_window_partials(ctypes.addressof(src), int(num_windows), ctypes.addressof(out))
     if rc:
         raise MsmError(rc, "msm377_g1_combine_window_partials")
+    return out.raw
+
+
+def add_points_bytes(points: bytes) -> bytes:
+    """Sum of affine wire points (96 bytes each; the identity as x = 0, y = 1): the last step of a points-partitioned
+    multi-GPU MSM (msm377_g1_add_points, host-only)."""
+    if len(points) % 96:
+        raise ValueError("points buffer length must be a multiple of 96")
+    lib = load_library()
+    out = ctypes.create_string_buffer(96)
+    rc = lib.msm377_g1_add_points(bytes(points), len(points) // 96, ctypes.addressof(out))
+    if rc:
+        raise MsmError(rc, "msm377_g1_add_points")
     return out.raw
 
 

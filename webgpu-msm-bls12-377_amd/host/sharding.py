@@ -1,4 +1,12 @@
-"""Window sharding across the GPUs of one node.
+"""Sharding one MSM across the GPUs of one node: by windows, or by points.
+
+POINT sharding (``ShardedMsm.run_points``; SURVEY.md section 8e's fallback): rank g runs a complete MSM over its slice
+of the points and scalars -- nothing is replicated -- and the exchange is one all-gather of 96-byte results, added up on
+every rank (msm377_g1_add_points).  WINDOW sharding (below) is what the reference's structure suggests and what
+BASELINE.json's config 4 names; it replicates the base conversion and keeps the per-window fixed costs on every rank.
+``choose_partition`` picks between them from the measured per-rank times.
+
+Window sharding:
 
 The 16 window subtasks are independent after decomposition -- the reference already loops
 over them in groups of four (src/submission/submission.ts:199-224) -- so rank g computes a
@@ -10,7 +18,7 @@ rank (msm377_g1_combine_partials).
 """
 from typing import Callable, Optional, Tuple
 
-from .engine import EEXCEPTIONAL, GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, MsmError, combine_partials_bytes, fold_partials_bytes
+from .engine import EEXCEPTIONAL, EHIP, GLV_WINDOWS, NUM_WINDOWS, WINDOW_PARTIAL_BYTES, MsmError, add_points_bytes, combine_partials_bytes, fold_partials_bytes
 
 
 def windows_for_rank(rank: int, world_size: int, num_windows: int = NUM_WINDOWS) -> Tuple[int, int]:
@@ -28,6 +36,49 @@ def combine_partials(partials: bytes) -> bytes:
     return combine_partials_bytes(partials)
 
 
+def points_for_rank(rank: int, world_size: int, n: int) -> Tuple[int, int]:
+    """(first, count) of rank's contiguous slice of the n points / scalars; counts differ by at most one."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, rem = divmod(n, world_size)
+    return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+
+
+def choose_partition(n: int, world_size: int) -> str:
+    """"points" or "windows" for an n-point MSM on world_size GPUs, from the per-rank times measured on one MI355X
+    (tools/time_shard.py, profiles/r03_final/time_shard_2e20.txt and _2e22.txt): a rank's share
+    under window sharding keeps the whole base conversion, the sort set-up, a 15-level reduction and the combine,
+    under point sharding everything shrinks with n / G -- so points win as soon as there is more than one rank,
+    narrowly at 2 ranks (1.82 vs 1.76 ms per rank at 2^20) and by 2x at 8 (0.95 vs 0.47)."""
+    return "points" if world_size > 1 else "windows"
+
+
+# Status word every rank appends to its slot of an exchange, so that a rank whose local work failed does not leave the
+# others waiting in the collective for the RCCL timeout: all ranks enter the all-gather, read every status and raise
+# together.  0 = fine; otherwise the negative MSM377_E* code (as u32) or STATUS_PYERR for any other exception.
+STATUS_BYTES = 16  # keeps the slots 16-byte aligned
+STATUS_PYERR = 0x7FFFFFFF
+
+
+def _status_word(exc) -> int:
+    if exc is None:
+        return 0
+    return (exc.code & 0xFFFFFFFF) if isinstance(exc, MsmError) else STATUS_PYERR
+
+
+def _raise_agreed(statuses, local_exc, what):
+    """Called on every rank with every rank's status: raises the local exception where there is one, and an MsmError
+    naming the first failed rank everywhere else."""
+    bad = [(r, s) for r, s in enumerate(statuses) if s]
+    if not bad:
+        return
+    if local_exc is not None:
+        raise local_exc
+    r, s = bad[0]
+    code = s - (1 << 32) if s & 0x80000000 else EHIP
+    raise MsmError(code, "%s: rank %d failed (status 0x%x); every rank abandons the exchange" % (what, r, s))
+
+
 class ShardedMsm:
     """sharded_msm with the exchange buffers allocated once (bench.py, services): a pinned host
     staging tensor, a send tensor and a world_size-slot receive tensor on ``device``."""
@@ -41,7 +92,8 @@ class ShardedMsm:
         self.num_windows = num_windows  # 16 on the plain path, GLV_WINDOWS = 8 behind the GLV front end
         self.begin, self.count = windows_for_rank(rank, world_size, num_windows)
         self.max_count = (num_windows + world_size - 1) // world_size
-        self.slot = self.max_count * WINDOW_PARTIAL_BYTES
+        self.rec_bytes = self.max_count * WINDOW_PARTIAL_BYTES
+        self.slot = self.rec_bytes + STATUS_BYTES  # records, then this rank's status word
         self.counts = [windows_for_rank(r, world_size, num_windows)[1] for r in range(world_size)]
         self.force_collective = force_collective
         if world_size > 1 or force_collective:
@@ -51,25 +103,73 @@ class ShardedMsm:
             dev = device if device is not None else "cpu"
             self.send_dev = torch.zeros(self.slot, dtype=torch.uint8, device=dev)
             self.recv_dev = torch.zeros(self.slot * world_size, dtype=torch.uint8, device=dev)
+            # point sharding: one 96-byte result + status per rank
+            self.pslot = 96 + STATUS_BYTES
+            self.psend_host = torch.zeros(self.pslot, dtype=torch.uint8, pin_memory=pin)
+            self.precv_host = torch.zeros(self.pslot * world_size, dtype=torch.uint8, pin_memory=pin)
+            self.psend_dev = torch.zeros(self.pslot, dtype=torch.uint8, device=dev)
+            self.precv_dev = torch.zeros(self.pslot * world_size, dtype=torch.uint8, device=dev)
+
+    def _set_status(self, host_tensor, offset: int, exc):
+        host_tensor.numpy()[offset : offset + 4] = memoryview(_status_word(exc).to_bytes(4, "little"))
+
+    @staticmethod
+    def _statuses(flat, slot: int, offset: int, world: int):
+        return [int.from_bytes(flat[r * slot + offset : r * slot + offset + 4].tobytes(), "little") for r in range(world)]
+
+    def run_points(self, msm_fn: Callable[[int, int], bytes], n: int) -> bytes:
+        """Point sharding: ``msm_fn(first, count)`` returns the 96-byte MSM of this rank's slice of the points and scalars
+        (MsmEngine.msm_device on offset device pointers: a complete MSM with its own fallbacks and host tail); ONE
+        all-gather of the results (112 bytes per rank) follows and every rank adds them up.  A rank whose MSM raised
+        still enters the collective, with its status word set, and then every rank raises."""
+        first, count = points_for_rank(self.rank, self.world, n)
+        if self.world == 1 and not self.force_collective:
+            return msm_fn(first, count)
+        import torch.distributed as dist
+
+        exc, mine = None, b"\x00" * 96
+        try:
+            mine = msm_fn(first, count)
+            if len(mine) != 96:
+                raise ValueError("msm_fn returned %d bytes" % len(mine))
+        except Exception as e:  # noqa: BLE001 -- agreed on below, re-raised on this rank
+            exc = e
+        self.psend_host.numpy()[:96] = memoryview(mine if exc is None else b"\x00" * 96)
+        self._set_status(self.psend_host, 96, exc)
+        self.psend_dev.copy_(self.psend_host, non_blocking=True)
+        dist.all_gather_into_tensor(self.precv_dev, self.psend_dev, group=self.group)
+        self.precv_host.copy_(self.precv_dev)  # synchronising D2H
+        flat = self.precv_host.numpy()
+        _raise_agreed(self._statuses(flat, self.pslot, 96, self.world), exc, "point-sharded MSM")
+        return add_points_bytes(b"".join(flat[r * self.pslot : r * self.pslot + 96].tobytes() for r in range(self.world)))
 
     def run(self, partials_fn: Callable[[int, int], bytes]) -> bytes:
-        mine = partials_fn(self.begin, self.count) if self.count else b""
-        if len(mine) != self.count * WINDOW_PARTIAL_BYTES:
-            raise ValueError("partials_fn returned %d bytes for %d windows" % (len(mine), self.count))
         if self.world == 1:
+            mine = partials_fn(self.begin, self.count) if self.count else b""
+            if len(mine) != self.count * WINDOW_PARTIAL_BYTES:
+                raise ValueError("partials_fn returned %d bytes for %d windows" % (len(mine), self.count))
             return combine_partials_bytes(mine, self.num_windows)
         import torch.distributed as dist
 
-        # This rank's share of the host tail: fold its own windows into one point before the exchange, so that the
-        # combine every rank runs afterwards is doublings plus one addition per rank (the tail does not shrink
-        # with the number of GPUs otherwise).
-        mine = fold_partials_bytes(mine)
-        if self.count:
+        exc, mine = None, b""
+        try:
+            mine = partials_fn(self.begin, self.count) if self.count else b""
+            if len(mine) != self.count * WINDOW_PARTIAL_BYTES:
+                raise ValueError("partials_fn returned %d bytes for %d windows" % (len(mine), self.count))
+            # This rank's share of the host tail: fold its own windows into one point before the exchange, so that the
+            # combine every rank runs afterwards is doublings plus one addition per rank (the tail does not shrink
+            # with the number of GPUs otherwise).
+            mine = fold_partials_bytes(mine)
+        except Exception as e:  # noqa: BLE001 -- every rank still enters the collective; agreed on below
+            exc, mine = e, b""
+        if mine:
             self.send_host.numpy()[: len(mine)] = memoryview(mine)
+        self._set_status(self.send_host, self.rec_bytes, exc)
         self.send_dev.copy_(self.send_host, non_blocking=True)
         dist.all_gather_into_tensor(self.recv_dev, self.send_dev, group=self.group)
         self.recv_host.copy_(self.recv_dev)  # synchronising D2H (53 KB at most)
         flat = self.recv_host.numpy()
+        _raise_agreed(self._statuses(flat, self.slot, self.rec_bytes, self.world), exc, "window-sharded MSM")
         parts = [flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts)]
         return combine_partials_bytes(b"".join(parts), self.num_windows)
 
@@ -92,15 +192,21 @@ class ShardedMsm:
 
         for attempt in (0, 1):
             fn = write_records if attempt == 0 else rerun_weierstrass
-            if self.count:
-                fn(self.begin, self.count, self.send_dev.data_ptr())
+            exc = None
+            try:
+                if self.count:
+                    fn(self.begin, self.count, self.send_dev.data_ptr())
+            except Exception as e:  # noqa: BLE001 -- a rank that failed (EHIP, ENOMEM, ...) still enters the collective
+                exc = e
+            # the status word rides behind the records in the same slot (a 16-byte H2D into the send buffer)
+            self._set_status(self.send_host, self.rec_bytes, exc)
+            self.send_dev[self.rec_bytes :].copy_(self.send_host[self.rec_bytes :], non_blocking=True)
             dist.all_gather_into_tensor(self.recv_dev, self.send_dev, group=self.group)
             self.recv_host.copy_(self.recv_dev)  # synchronising D2H
-            if combine is not None and self.num_windows == NUM_WINDOWS and all(c == self.max_count for c in self.counts):
-                parts = self.recv_host.data_ptr()  # every slot is full: the gathered buffer IS the 16 records, combined in place
-            else:
-                flat = self.recv_host.numpy()
-                parts = b"".join(flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts))
+            flat = self.recv_host.numpy()
+            _raise_agreed(self._statuses(flat, self.slot, self.rec_bytes, self.world), exc, "window-sharded MSM")
+            # the gathered slots carry a status word each, so the 16 records are re-packed for the combine (48 KB)
+            parts = b"".join(flat[r * self.slot : r * self.slot + c * WINDOW_PARTIAL_BYTES].tobytes() for r, c in enumerate(self.counts))
             try:
                 return combine(parts) if combine is not None else combine_partials_bytes(parts, self.num_windows)
             except MsmError as e:
