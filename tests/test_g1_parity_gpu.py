@@ -616,6 +616,35 @@ def test_window_sharding_on_one_gpu(engine, oracle, world):
     assert msm.combine_partials(b"".join(parts)) == util.oracle_msm(oracle, pts, ks)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_point_sharding_on_one_gpu(engine, oracle, world):
+    """The other partitioning of a multi-GPU run (host/sharding.py run_points): every rank's slice of the points run as
+    a complete MSM on this one GPU -- slices of a few hundred points (narrow windows) and of thousands (16-bit windows),
+    one of them holding the point at infinity's neighbours: an all-zero scalar slice gives the identity -- and the rank
+    results added by msm377_g1_add_points equal the oracle's MSM of everything."""
+    from webgpu_msm_bls12_377_amd.host.sharding import points_for_rank
+    from webgpu_msm_bls12_377_amd.host.engine import add_points_bytes
+
+    n = 70000 if world == 3 else 6001
+    pts, ks = seeded_inputs(oracle, n, 89)
+    first, count = points_for_rank(world - 1, world, n)
+    ks = ks[: 32 * first] + b"\x00" * (32 * count)  # the last rank's scalars are all zero: its result is the identity (0, 1)
+    d_p, d_s = dev(pts), dev(ks)
+    results = []
+    for r in range(world):
+        f, c = points_for_rank(r, world, n)
+        results.append(engine.msm_device(d_p.data_ptr() + 96 * f, d_s.data_ptr() + 32 * f, c))
+    assert results[-1] == bytes(48) + b"\x01" + bytes(47)
+    assert add_points_bytes(b"".join(results)) == util.oracle_msm(oracle, pts, ks)
+    # P + (-P) and P + P through the host addition
+    one = results[0]
+    neg = one[:48] + ((R.P - int.from_bytes(one[48:], "little")) % R.P).to_bytes(48, "little")
+    assert add_points_bytes(one + neg) == bytes(48) + b"\x01" + bytes(47)
+    assert add_points_bytes(one + one) == R.encode_result(R.add(R.decode_result(one), R.decode_result(one)))
+    with pytest.raises(msm.MsmError):
+        add_points_bytes(b"\xff" * 96)  # a coordinate that is not below p
+
+
 @pytest.mark.parametrize(
     "knobs",
     [

@@ -200,3 +200,35 @@ def test_exceptional_records_are_recomputed_on_every_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def test_add_points_host_function():
+    """msm377_g1_add_points (the last step of a point-sharded run), host-only: sums of affine wire points against Python
+    big integers, the identity as the wire format writes it, P + P, P + (-P), and a coordinate that is not below p."""
+    import pyref as R
+    from webgpu_msm_bls12_377_amd.host.engine import add_points_bytes
+    from webgpu_msm_bls12_377_amd.host.sharding import points_for_rank
+
+    rnd = random.Random(11)
+    pts = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(9)]
+    ident = bytes(48) + b"\x01" + bytes(47)
+    acc = None
+    for p in pts:
+        acc = p if acc is None else R.add(acc, p)
+    wire = b"".join(R.encode_result(p) for p in pts)
+    assert add_points_bytes(wire) == R.encode_result(acc)
+    assert add_points_bytes(ident + wire[:96] + ident + wire[96:] + ident) == R.encode_result(acc)
+    assert add_points_bytes(b"") == ident and add_points_bytes(ident * 3) == ident
+    p0 = wire[:96]
+    neg = p0[:48] + (R.P - int.from_bytes(p0[48:], "little")).to_bytes(48, "little")
+    assert add_points_bytes(p0 + neg) == ident
+    assert add_points_bytes(p0 + p0) == R.encode_result(R.add(pts[0], pts[0]))
+    assert add_points_bytes(p0 + p0 + neg + neg) == ident
+    with pytest.raises(msm.MsmError) as e:
+        add_points_bytes(p0 + R.P.to_bytes(48, "little") + bytes(48))
+    assert e.value.code == -1
+    for world in range(1, 12):  # the slices tile [0, n) for every world size, including more ranks than points
+        for n in (0, 1, 7, 100, 1 << 20):
+            spans = [points_for_rank(r, world, n) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            assert all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(world - 1))

@@ -8,7 +8,7 @@ n = 1 << 20
 d_points = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
 scal = bench.seeded_scalars(0x5CA1A5, n)
 engs = {}
-for name, v, split, k in (("4 chunks 30", "262144", "30", "4"), ("5 chunks 25", "262144", "25", "5"), ("6 chunks 20", "262144", "20", "6"), ("8 chunks 15", "262144", "15", "8"), ("4 chunks 25", "262144", "25", "4"), ("whole", "99999999999", "50", "2")):
+for name, v, split, k in (("5 chunks 16", "262144", "16", "5"), ("4 chunks 20", "262144", "20", "4"), ("6 chunks 12", "262144", "12", "6"), ("5 chunks 10", "262144", "10", "5"), ("5 chunks 22", "262144", "22", "5"), ("8 chunks 10", "262144", "10", "8"), ("3 chunks 25", "262144", "25", "3"), ("whole", "99999999999", "50", "2")):
     os.environ["MSM377_UPLOAD_CHUNK_MIN"] = v
     os.environ["MSM377_UPLOAD_SPLIT"] = split
     os.environ["MSM377_UPLOAD_CHUNKS"] = k

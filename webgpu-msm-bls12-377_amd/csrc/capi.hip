@@ -53,7 +53,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
   if (const char* e = getenv("MSM377_H2D_THREADS")) ctx->h2d_threads = std::min(std::max(atoi(e), 1), 8);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 8);
-  if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 10), 90);
+  if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 5), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = std::min(std::max(atoi(e), 1), TailPool::WORKERS + 1);
@@ -65,7 +65,6 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
   if (const char* e = getenv("MSM377_NARROW_MAX")) ctx->narrow_max_points = strtoull(e, nullptr, 10);
-  if (const char* e = getenv("MSM377_TABLE_PREFETCH")) ctx->table_prefetch = atoi(e);
   if (const char* e = getenv("MSM377_PRECOMP_BITS")) ctx->precomp_bits = atoi(e) == (int)WIDE_BITS ? (int)WIDE_BITS : MSM377_WINDOW_BITS;
   if (const char* e = getenv("MSM377_AFF_AFTER_SORT")) ctx->aff_down_after_sort = atoi(e);
   if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
@@ -159,7 +158,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table, ctx->d_wide_digits, ctx->d_wide_counts};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table, ctx->d_wide_digits, ctx->d_wide_counts, ctx->d_wide_temp, ctx->d_row_ptr_chunks};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);

@@ -49,6 +49,18 @@ struct WorkItem {
   uint32_t row;  // ws * NB + t   (bucket index t <-> key t + 1)
   uint32_t seg;  // entries [seg * seglen, seg * seglen + seglen) of the row, see row_split
 };
+// The CSR rows of a call whose points arrive in K chunks (host-buffer entry point, sequencer.hip run_sorted_upload): the
+// sort files every key's entries by chunk, row_ptr holds K sub-row bounds per key -- entry (key, c) at index key K + c of
+// a window's ((2^L + 1) K + 1) offsets -- and a launch walks ONE chunk's sub-rows.  K = 1, c = 0: the plain layout
+// (2^L + 2 offsets per window, row t = key t + 1 at [t + 1, t + 2)).
+struct RowView {
+  uint32_t k = 1, c = 0;
+};
+constexpr uint32_t MAX_UPLOAD_CHUNKS = 8;
+struct ChunkCuts {  // chunk j of the points = indices [cut[j], cut[j + 1]); cut[0] = 0, entries from k on = n
+  uint32_t k = 1;
+  uint32_t cut[MAX_UPLOAD_CHUNKS + 1] = {};
+};
 constexpr uint32_t META_BLOCK_WORDS = 2 * SEG_BINS + 4 + MSM377_NUM_WINDOWS;  // per pipeline part: work-list counters + key_max words
 constexpr size_t SLOT_WORDS = (size_t)MAX_WINDOW_SLOTS * MSM377_G1_PARTIAL_POINTS * MSM377_G1_POINT_WORDS;  // per double-buffer slot of partial records
 

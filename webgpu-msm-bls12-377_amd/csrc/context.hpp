@@ -34,6 +34,7 @@ struct msm377_ctx {
   uint32_t* d_region_base = nullptr;  // 16 x (NRANGE + 1)
   SortElem* d_sort_temp = nullptr;    // 16 x cap partitioned (index|sign, key) pairs
   uint32_t* d_row_ptr = nullptr;      // 16 x RP
+  uint32_t* d_row_ptr_chunks = nullptr; // 16 x ((NB + 1) x 8 + 1): rows filed by upload chunk (run_sorted_upload; allocated on first use)
   uint32_t* d_val_idx = nullptr;      // 16 x cap
   uint32_t* d_buckets = nullptr;      // 16 x 52 x NB
   uint32_t* d_buckets_snap = nullptr; // stage capture only
@@ -47,9 +48,9 @@ struct msm377_ctx {
   uint64_t table_cap = 0;
   uint32_t table_windows = 0;         // windows the allocated table holds (16, or WIDE_WINDOWS)
   int precomp_bits = MSM377_WINDOW_BITS;  // window width msm377_g1_set_bases_precomputed builds its next table for: 16 or 20 (msm377_ctx_set_precompute_window, MSM377_PRECOMP_BITS)
-  int table_prefetch = 1;             // MSM377_TABLE_PREFETCH=0: precomputed tables gather with the main path's prefetch depth (k_accumulate PF = 0)
   uint32_t* d_wide_digits = nullptr;  // wide windows: 13 x n u32 biased 20-bit digits, the flat list the sort reads
-  uint32_t* d_wide_counts = nullptr;  // wide windows: MAX_SORT_BLOCKS x 4096 per-chunk range counts, then 4096 range totals
+  SortElem* d_wide_temp = nullptr;    // wide windows: the elements between the two partition passes (pass A writes d_sort_temp, pass B this)
+  uint32_t* d_wide_counts = nullptr;  // wide windows: the two passes' per-workgroup stream counts / offsets and the coarse region bounds
   uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
   uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
   uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
@@ -123,8 +124,8 @@ struct msm377_ctx {
   hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
   hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
-  uint32_t upload_chunks = 4;              // chunks of the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..8): 2: 5.07, 3: 4.89, 4-6: 4.70, 8: 4.95 ms at 2^20
-  uint32_t upload_split_pct = 30;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 10..90)
+  uint32_t upload_chunks = 5;              // chunks of the points in the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..8)
+  uint32_t upload_split_pct = 16;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 5..90): it should land when the sort of the scalars is through
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;

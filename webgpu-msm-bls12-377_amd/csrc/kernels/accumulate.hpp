@@ -22,9 +22,14 @@ namespace {
 // skewed scalars -- the load balancing the reference left out, README.md:543-547).
 
 
-__device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t row) {
-  const uint32_t* rp = row_ptr + (size_t)(row >> L) * ((1u << L) + 2) + (row & ((1u << L) - 1));
-  return rp[2] - rp[1];
+// [0], [1]: begin and end of bucket t's row in window slot ws -- of its sub-row rv.c when the rows are filed by upload
+// chunk (common.hpp RowView).
+__device__ __forceinline__ const uint32_t* row_bounds(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t ws, uint32_t t, RowView rv) {
+  return row_ptr + (size_t)ws * (((1u << L) + 1) * rv.k + 1) + (size_t)(t + 1) * rv.k + rv.c;
+}
+__device__ __forceinline__ uint32_t row_len(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t row, RowView rv) {
+  const uint32_t* b = row_bounds(row_ptr, L, row >> L, row & ((1u << L) - 1), rv);
+  return b[1] - b[0];
 }
 
 // A row of `len` entries becomes `nseg` work items of `seglen` entries (the last one `lastlen`): equal parts of at
@@ -50,7 +55,7 @@ __device__ __forceinline__ RowSplit row_split(uint32_t len, uint32_t SEG) {
 // atomic per bin and block -- the ~60 hot counters serialise, hence the large blocks); rows with more than one item reserve overflow slots and join the split-row list.
 __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ work_hist,
                                                    uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
-                                                   uint32_t* __restrict__ split_rows) {
+                                                   uint32_t* __restrict__ split_rows, RowView rv) {
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t blk[4];  // split rows, overflow slots of this block; then their bases in the global lists
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
@@ -60,7 +65,7 @@ __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__
   RowSplit sp = {1, 0, 0};
   uint32_t my_split = 0, my_ovf = 0;
   if (row < rows) {
-    sp = row_split(row_len(row_ptr, L, row), SEG);
+    sp = row_split(row_len(row_ptr, L, row, rv), SEG);
     atomicAdd(&lh[sp.lastlen], 1u);
     if (sp.nseg > 1) {
       atomicAdd(&lh[sp.seglen], sp.nseg - 1);
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ 
 
 // Thread per row again: claims its slots in the sorted work list.
 __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ cursor,
-                                                      WorkItem* __restrict__ work) {
+                                                      WorkItem* __restrict__ work, RowView rv) {
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t lbase[SEG_BINS];
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
@@ -108,7 +113,7 @@ __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restric
   RowSplit sp = {0, 0, 0};
   uint32_t rank_full = 0, rank_last = 0;
   if (row < rows) {
-    sp = row_split(row_len(row_ptr, L, row), SEG);
+    sp = row_split(row_len(row_ptr, L, row, rv), SEG);
     if (sp.nseg > 1) rank_full = atomicAdd(&lh[sp.seglen], sp.nseg - 1);
     rank_last = atomicAdd(&lh[sp.lastlen], 1u);
   }
@@ -127,16 +132,16 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ buckets, uint64_t n,
                                                        const WorkItem* __restrict__ work, const uint32_t* __restrict__ work_total,
                                                        const uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into, uint64_t table_stride, uint32_t L) {
+                                                       int* __restrict__ err, const int* __restrict__ conv_err, uint32_t into, uint64_t table_stride, uint32_t L, RowView rv) {
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v == 0 && *conv_err) atomicOr(err, *conv_err);  // the table holds a point its coordinate system cannot represent
   if (v >= *work_total) return;
   const WorkItem it = work[v];
   const uint32_t ws = it.row >> L, t = it.row & ((1u << L) - 1);
-  const uint32_t* rp = row_ptr + (size_t)ws * ((1u << L) + 2);
+  const uint32_t* rb = row_bounds(row_ptr, L, ws, t, rv);
   const uint32_t* vi = val_idx + (size_t)ws * n;
   bases += (size_t)ws * table_stride * BP::REC_WORDS;  // precomputed-window tables: window slot ws gathers from its own copy, [2^(16 ws)] P_i
-  const uint32_t row_beg = rp[t + 1], row_end = rp[t + 2];
+  const uint32_t row_beg = rb[0], row_end = rb[1];
   const uint32_t seglen = row_split(row_end - row_beg, SEG).seglen;
   uint32_t k = row_beg + it.seg * seglen;
   const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
@@ -149,9 +154,9 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
     // Software pipeline: while entry k is added the record of entry k+PF+1 is on its way (its gather is issued at the
     // start of the stage), the records of entries k+1 .. k+PF have been requested one to PF additions ago, and the index
     // of entry k+PF+2 is being read -- so neither the val_idx -> bases address dependency nor the gather latency stalls
-    // the wave.  PF = 0 on the main path (one addition, ~10 us, covers a gather from the 168 MB table, which lives in
-    // the Infinity Cache across the 16 windows' passes); PF = 1 is for the gigabyte tables of precomputed window
-    // multiples, whose gathers come from HBM (+40 VGPRs).
+    // the wave.  PF = 0 everywhere: one addition, ~10 us, covers a gather even from the 2.2 GB tables of precomputed
+    // window multiples, which miss the Infinity Cache -- PF = 1 (one more record in flight, 252 VGPRs) was measured on
+    // the 20-bit-window table: kernel 1.388 -> 1.435 ms, 64 x 2^20 batch 2.199 -> 2.274 ms per MSM.
     typename BP::Base rec[PF + 1];  // rec[0]: the entry being added
     uint32_t e[PF + 2];             // e[j]: entry of rec[j]; e[PF + 1]: the next index, already loaded
 #pragma unroll
@@ -203,11 +208,11 @@ template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
                                                              const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                             int* __restrict__ err, uint32_t L) {
+                                                             int* __restrict__ err, uint32_t L, RowView rv) {
   const uint32_t count = counters[0];
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
     const uint32_t row = split_rows[i];
-    const uint32_t len = row_len(row_ptr, L, row);
+    const uint32_t len = row_len(row_ptr, L, row, rv);
     const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row >> L, t = row & ((1u << L) - 1);
     typename CV::Pt acc = load_bucket<CV>(buckets, L, ws, t);
@@ -259,9 +264,9 @@ __global__ void __launch_bounds__(256, 2) k_accumulate_quad(const uint32_t* __re
   if (v >= *work_total) return;  // whole quads leave together
   const WorkItem it = work[v];
   const uint32_t ws = it.row >> L, t = it.row & ((1u << L) - 1);
-  const uint32_t* rp = row_ptr + (size_t)ws * ((1u << L) + 2);
+  const uint32_t* rb = row_bounds(row_ptr, L, ws, t, RowView{});
   const uint32_t* vi = val_idx + (size_t)ws * n;
-  const uint32_t row_beg = rp[t + 1], row_end = rp[t + 2];
+  const uint32_t row_beg = rb[0], row_end = rb[1];
   const uint32_t seglen = row_split(row_end - row_beg, SEG).seglen;
   uint32_t k = row_beg + it.seg * seglen;
   const uint32_t end = (row_end - k > seglen) ? k + seglen : row_end;
@@ -317,12 +322,12 @@ template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
                                                                   const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                                  int* __restrict__ err, uint32_t L) {
+                                                                  int* __restrict__ err, uint32_t L, RowView rv) {
   const uint32_t count = counters[0];
   const uint32_t q = threadIdx.x & 3;
   for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {
     const uint32_t row = split_rows[i];
-    const uint32_t len = row_len(row_ptr, L, row);
+    const uint32_t len = row_len(row_ptr, L, row, rv);
     const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row >> L, t = row & ((1u << L) - 1);
     typename CV::Pt acc = load_bucket<CV>(buckets, L, ws, t);

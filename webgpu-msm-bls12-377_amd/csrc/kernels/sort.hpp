@@ -194,25 +194,42 @@ __global__ void __launch_bounds__(1024) k_partition_staged(const uint16_t* __res
 // A/B at 2^20: sort stage 0.344 -> 0.296 ms, whole MSM 2.60 -> 2.55).  Longer regions (skewed scalars) are streamed twice.
 constexpr uint32_t LS_CACHE = 6144;           // region length (n / 256 = 4096 on average at n = 2^20) the register / LDS path holds
 constexpr uint32_t LS_REG = LS_CACHE / 256;  // elements per thread
+// CH: the rows are filed by upload chunk as well (common.hpp RowView / ChunkCuts; the host-buffer entry point): bin
+// (key, chunk of the point index) instead of key, K sub-row bounds per key in row_ptr.  CH = false compiles to the
+// plain layout.
+template <bool CH>
 __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
                                                         uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
-                                                        const uint32_t* __restrict__ key_max, uint32_t NR, uint32_t NBK) {
+                                                        const uint32_t* __restrict__ key_max, uint32_t NR, uint32_t NBK, ChunkCuts cuts) {
   // NR ranges per window over keys 0 .. NBK (256 x 2^15 on the main path; 4096 x 2^19, one window, no key_max, for the
   // wide windows of kernels/wide.hpp); the last range also owns key NBK.
-  const uint32_t RPW = NBK + 2;  // row_ptr entries per window
-  __shared__ uint32_t bins[KRANGE + 1];
+  constexpr uint32_t MAXK = CH ? MAX_UPLOAD_CHUNKS : 1;
+  constexpr uint32_t NBINS = (KRANGE + 1) * MAXK, PER = (NBINS + 255) / 256;  // bins a thread owns in the scan
+  __shared__ uint32_t bins[NBINS];
   __shared__ uint32_t part[256];
   __shared__ uint32_t sorted[LS_CACHE];
+  const uint32_t K = CH ? cuts.k : 1u;
+  const uint32_t RPW = (NBK + 1) * K + 1;  // row_ptr entries per window
   const uint32_t r = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
   const uint32_t shift = key_max ? win_shift(key_max[ws]) : 0u;
   const uint32_t KR = KRANGE >> shift;  // keys per range in this window
   const uint32_t lo = r * KR;
   const bool last = shift == 0 && r == NR - 1;  // only the full-width layout reaches key NBK
+  const uint32_t nb = (KR + (last ? 1u : 0u)) * K;  // bins in use: (key - lo, chunk)
   const uint32_t rbeg = region_base[ws * (NR + 1) + r], rend = region_base[ws * (NR + 1) + r + 1];
   const uint32_t len = rend - rbeg;
   const bool cached = len <= LS_CACHE;
   const SortElem* in = temp + (size_t)ws * n + rbeg;
-  if (tid <= KRANGE) bins[tid] = 0;
+  auto bin_of = [&](const SortElem& e) {
+    uint32_t b = (e.key - lo) * K;
+    if (CH) {
+      const uint32_t idx = e.idx_sign & 0x7fffffffu;
+#pragma unroll
+      for (uint32_t j = 1; j < MAXK; j++) b += (j < K && idx >= cuts.cut[j]) ? 1u : 0u;
+    }
+    return b;
+  };
+  for (uint32_t b = tid; b < NBINS; b += 256) bins[b] = 0;
   __syncthreads();
   SortElem e[LS_REG];
   if (cached) {
@@ -225,7 +242,7 @@ __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restri
     }
 #pragma unroll
     for (uint32_t u = 0; u < LS_REG; u++)
-      if (u * 256 + tid < len) atomicAdd(&bins[e[u].key - lo], 1u);
+      if (u * 256 + tid < len) atomicAdd(&bins[bin_of(e[u])], 1u);
   } else {
     for (uint32_t i0 = 0; i0 < len; i0 += 2048) {
       SortElem f[8];
@@ -233,16 +250,24 @@ __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restri
       for (int u = 0; u < 8; u++) {
         const uint32_t i = i0 + u * 256 + tid;
         f[u].key = lo;
+        f[u].idx_sign = 0;
         if (i < len) f[u] = in[i];
       }
 #pragma unroll
       for (int u = 0; u < 8; u++)
-        if (i0 + u * 256 + tid < len) atomicAdd(&bins[f[u].key - lo], 1u);
+        if (i0 + u * 256 + tid < len) atomicAdd(&bins[bin_of(f[u])], 1u);
     }
   }
   __syncthreads();
-  const uint32_t own = tid < KR ? bins[tid] : 0u;
-  part[tid] = own;
+  // exclusive scan over the bins in use: a thread owns PER consecutive bins
+  uint32_t own[PER], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t b = tid * PER + k;
+    own[k] = b < nb ? bins[b] : 0u;
+    sum += own[k];
+  }
+  part[tid] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < 256; off <<= 1) {
     const uint32_t v = tid >= off ? part[tid - off] : 0u;
@@ -250,20 +275,21 @@ __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restri
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t* rp = row_ptr + (size_t)ws * RPW + lo;
-  const uint32_t start = rbeg + part[tid] - own;
+  uint32_t* rp = row_ptr + (size_t)ws * RPW + (size_t)lo * K;  // bin b of this range is offset lo K + b of the window
+  uint32_t start = rbeg + part[tid] - sum;
   __syncthreads();
-  if (tid < KR) {
-    bins[tid] = start;
-    rp[tid] = start;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t b = tid * PER + k;
+    if (b < nb) {
+      bins[b] = start;  // becomes the write cursor of the bin
+      rp[b] = start;
+      start += own[k];
+    }
   }
-  if (tid == KRANGE - 1 && last) {  // key 32768 and the end sentinel
-    bins[KRANGE] = start + own;
-    rp[KRANGE] = start + own;
-    rp[KRANGE + 1] = rend;
-  }
+  if (tid == 0 && last) rp[nb] = rend;  // the end sentinel behind key NBK
   if (shift) {  // narrowed ranges cover keys below NR * KR only: every row above is empty and starts at the end
-    const uint32_t covered = NR * KR, total = region_base[ws * (NR + 1) + NR];
+    const uint32_t covered = NR * KR * K, total = region_base[ws * (NR + 1) + NR];
     const uint32_t per_block = (RPW - covered + NR - 1) / NR;
     uint32_t* rp_w = row_ptr + (size_t)ws * RPW;
     for (uint32_t j = tid; j < per_block; j += 256) {
@@ -276,7 +302,7 @@ __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restri
   if (cached) {
 #pragma unroll
     for (uint32_t u = 0; u < LS_REG; u++)
-      if (u * 256 + tid < len) sorted[atomicAdd(&bins[e[u].key - lo], 1u) - rbeg] = e[u].idx_sign;
+      if (u * 256 + tid < len) sorted[atomicAdd(&bins[bin_of(e[u])], 1u) - rbeg] = e[u].idx_sign;
     __syncthreads();
     for (uint32_t i = tid; i < len; i += 256) vi[rbeg + i] = sorted[i];
   } else {
@@ -285,12 +311,14 @@ __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restri
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t i = i0 + u * 256 + tid;
+        f[u].key = lo;
+        f[u].idx_sign = 0;
         if (i < len) f[u] = in[i];
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t i = i0 + u * 256 + tid;
-        if (i < len) vi[atomicAdd(&bins[f[u].key - lo], 1u)] = f[u].idx_sign;
+        if (i < len) vi[atomicAdd(&bins[bin_of(f[u])], 1u)] = f[u].idx_sign;
       }
     }
   }

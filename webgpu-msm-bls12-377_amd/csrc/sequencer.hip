@@ -252,6 +252,14 @@ struct Phase {
   // Wide windows over a precomputed table (kernels/wide.hpp): `table` holds [2^(20 w)] P_i for 13 windows, the call has
   // ONE window slot of 2^19 buckets fed by the flat list of 13 n digits (cbits = WIDE_BITS, bucket_log = WIDE_LOG).
   bool wide = false;
+  // Points that arrive in chunks (run_sorted_upload): ONE decomposition and sort of all scalars files every row's entries
+  // by chunk (`cuts`), then each chunk's accumulation phase walks its own sub-rows (`chunk`) once its points are on the
+  // device.  sort / accumulate select which half of the front phase a call enqueues.
+  bool sort = true;        // decompose + sort
+  bool accumulate = true;  // work list, accumulation, merge of split rows
+  ChunkCuts cuts;          // cuts.k > 1: rows filed by chunk
+  uint32_t chunk = 0;      // the chunk this phase accumulates
+  uint64_t chunk_points = 0;  // its points (work-item length), 0 = all n
 };
 
 struct PartView {
@@ -265,10 +273,12 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
                  uint32_t sort_blocks, const Phase& ph) {
   hipStream_t st = pv.st;
   const uint32_t wc = pv.wc, part = pv.part;
-  const uint32_t L = ph.bucket_log, NB = 1u << L, RP = NB + 2;  // this call's bucket geometry (shadows the main path's constants)
+  const uint32_t L = ph.bucket_log, NB = 1u << L;  // this call's bucket geometry (shadows the main path's constant)
+  const RowView rv{ph.cuts.k, ph.chunk};
+  const uint32_t RP = (NB + 1) * rv.k + 1;  // row_ptr entries per window slot (NB + 2 for plain rows)
   const bool wide = ph.wide;
   const bool narrow = !wide && ph.cbits != MSM377_WINDOW_BITS;
-  const uint64_t entries = wide ? (uint64_t)WIDE_WINDOWS * n : (uint64_t)wc * n;  // (window, point) pairs of this part
+  const uint64_t entries = wide ? (uint64_t)WIDE_WINDOWS * n : (uint64_t)wc * (ph.chunk_points ? ph.chunk_points : n);  // (window, point) pairs this phase accumulates
   static_assert((uint64_t)NARROW_WINDOWS * SMALL_SORT_MAX / NARROW_SEG + NARROW_WINDOWS * (1u << NARROW_LOG) <= (uint64_t)MSM377_NUM_WINDOWS * 32768, "narrow work items fit the work-item buffer");
   // per launch: each part must fill the GPU on its own.  Narrow windows: a small input is all latency -- a work item is
   // a serial chain of ~10 us additions -- so its chains are cut at 8 entries (the buffers, sized for 16 windows of
@@ -278,7 +288,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   uint32_t* range_counts = ctx->d_range_counts + (size_t)part * NRANGE * (MAX_SORT_BLOCKS / 2);
   uint32_t* region_base = ctx->d_region_base + (size_t)pv.ws0 * (NRANGE + 1);
   SortElem* sort_temp = ctx->d_sort_temp + (size_t)pv.ws0 * n;
-  uint32_t* row_ptr = ctx->d_row_ptr + (size_t)pv.ws0 * RP;
+  uint32_t* row_ptr = (rv.k > 1 ? ctx->d_row_ptr_chunks : ctx->d_row_ptr) + (size_t)pv.ws0 * RP;
   uint32_t* val_idx = ctx->d_val_idx + (size_t)pv.ws0 * n;
   uint32_t* buckets = ctx->d_buckets + (size_t)pv.ws0 * CV::BKT_WORDS * NB;
   uint32_t* row_ovf_base = ctx->d_row_ovf_base + (size_t)pv.ws0 * NB;
@@ -301,6 +311,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // work items itself, one global atomic per list and workgroup -- was built and dropped: 0.271 -> 0.293 ms at 2^12,
   // 0.342 -> 0.373 at 2^14.  Saving four dispatch latencies did not pay for a work list that is sorted by length
   // only within each window: the accumulation kernel went from 0.038 to 0.054 ms at 2^12.)
+  if (ph.sort) {
   {
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (wide)
@@ -314,21 +325,27 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
   }
 
-  if (wide) {  // one counting sort of the 13 n entries by key: 4096 ranges, then k_local_sort_lds per range
+  if (wide) {  // one counting sort of the 13 n entries by key: two radix-64 passes (kernels/wide.hpp), then k_local_sort_lds per range
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
     const uint64_t N = entries;
     uint32_t chunks = MAX_SORT_BLOCKS;
     const uint64_t want = (N + 8191) / 8192;
     if (chunks > want) chunks = (uint32_t)(want ? want : 1);
-    const uint64_t per_chunk = ((N + chunks - 1) / chunks + 3) & ~3ull;  // whole 16-byte groups of digits
-    uint32_t* counts = ctx->d_wide_counts;
-    uint32_t* tot = counts + (size_t)MAX_SORT_BLOCKS * WIDE_NRANGE;
-    hipLaunchKernelGGL(k_wide_count, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, N, per_chunk);
-    hipLaunchKernelGGL(k_wide_total, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, tot, chunks);
-    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, tot, region_base);
-    hipLaunchKernelGGL(k_wide_offsets, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, region_base, chunks);
-    hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk, (uint32_t)n, (uint32_t)ph.table_stride);
-    hipLaunchKernelGGL(k_local_sort_lds, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB);
+    const uint64_t per_chunk = ((N + chunks - 1) / chunks + 7) & ~7ull;  // whole 16-byte groups of digits
+    uint32_t* countsA = ctx->d_wide_counts;                                   // [chunks][64]
+    uint32_t* countsB = countsA + (size_t)MAX_SORT_BLOCKS * WP_R;             // [64 regions][WP_BCHUNKS][64]
+    uint32_t* regionA = countsB + (size_t)WP_R * WP_BCHUNKS * WP_R;           // 65 bounds of the coarse regions
+    SortElem* tempB = ctx->d_wide_temp;
+    const WideFromDigits srcA{ctx->d_wide_digits, (uint32_t)n, (uint32_t)ph.table_stride};
+    const WideFromElems srcB{sort_temp};
+    hipLaunchKernelGGL(k_wide_count<WideFromDigits>, dim3(chunks, 1), dim3(1024), 0, st, srcA, (const uint32_t*)nullptr, countsA, N, per_chunk);
+    hipLaunchKernelGGL(k_wide_scan_a, dim3(1), dim3(1024), 0, st, countsA, regionA, chunks);
+    hipLaunchKernelGGL(k_wide_scatter<WideFromDigits>, dim3(chunks, 1), dim3(1024), 0, st, srcA, (const uint32_t*)nullptr, (const uint32_t*)countsA, sort_temp, N, per_chunk);
+    hipLaunchKernelGGL(k_wide_count<WideFromElems>, dim3(WP_BCHUNKS, WP_R), dim3(1024), 0, st, srcB, (const uint32_t*)regionA, countsB, N, per_chunk);
+    hipLaunchKernelGGL(k_wide_scan_b, dim3(WP_R), dim3(WP_R), 0, st, countsB, (const uint32_t*)regionA, region_base);
+    hipLaunchKernelGGL(k_wide_scatter<WideFromElems>, dim3(WP_BCHUNKS, WP_R), dim3(1024), 0, st, srcB, (const uint32_t*)regionA, (const uint32_t*)countsB, tempB, N, per_chunk);
+    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, (const SortElem*)tempB, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr,
+                       WIDE_NRANGE, NB, ChunkCuts{});
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   } else if (narrow) {
@@ -348,11 +365,15 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_partition_staged, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk, key_max);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_local_sort_lds, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB);
+    if (rv.k > 1)  // rows filed by upload chunk: K sub-row bounds per key
+      hipLaunchKernelGGL(k_local_sort_lds<true>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ph.cuts);
+    else
+      hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ChunkCuts{});
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   }
-  {
+  }  // ph.sort
+  if (ph.accumulate) {
     StageTimer t(ctx, MSM377_STAGE_ACCUMULATE, st, part);
     const uint32_t rows = wc * NB;
     uint32_t* meta = meta_block;
@@ -360,11 +381,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     uint32_t* cursor = meta + SEG_BINS;
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
-    hipLaunchKernelGGL(k_work_hist, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, work_hist, row_ovf_base, counters, split_rows);
+    hipLaunchKernelGGL(k_work_hist, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, work_hist, row_ovf_base, counters, split_rows, rv);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work);
+    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work, rv);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->before_accumulate) {  // must run before the wait below is queued: the wait binds to the event's latest record
       std::function<int()> f;
@@ -390,17 +411,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       }
       if (launched) {
       } else if constexpr (!std::is_same<BP, CV>::value)
-      {
-        if (ph.table && ctx->table_prefetch)  // gigabyte table: gathers come from HBM, one more record in flight
-          hipLaunchKernelGGL((k_accumulate<CV, 2, BP, 1>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                             ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
-        else
-          hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                             ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
-      }
+        hipLaunchKernelGGL((k_accumulate<CV, 2, BP>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L, rv);
       else
         hipLaunchKernelGGL((k_accumulate<CV, 2>), grid, dim3(256), 0, st, row_ptr, val_idx, bases, buckets, n, work, total, row_ovf_base, ovf, SEG, d_err,
-                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L);
+                           ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L, rv);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
@@ -408,15 +423,15 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     if constexpr (CV::HAS_QUAD) {
       if (ctx->merge_quad) {
         hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? (rows + 63) / 64 : 4 * MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
-                           row_ovf_base, ovf, SEG, d_err, L);
+                           row_ovf_base, ovf, SEG, d_err, L, rv);
         merged = true;
       }
     }
     if (!merged)
       hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? (rows + 255) / 256 : MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
-                         row_ovf_base, ovf, SEG, d_err, L);
+                         row_ovf_base, ovf, SEG, d_err, L, rv);
     HIP_TRY(ctx, hipGetLastError());
-  }
+  }  // ph.accumulate
   }  // ph.front
   if (!ph.back) return MSM377_OK;
   if (ctx->capture) {
@@ -762,56 +777,86 @@ int resident_table_to_weierstrass(msm377_ctx* ctx) {
   return MSM377_OK;
 }
 
-// Host-buffer entry points with large inputs: the upload (2.9 ms for 2^20 G1 points from pageable memory) is as
-// long as the whole computation, so the MSM runs as K chunks of points: a chunk's decompose .. accumulate .. merge
-// runs while the next one is on its way, later chunks accumulate on top of the buckets (Phase::into), and reduction,
-// gather and D2H are queued once, with the last chunk.  Returns with everything enqueued (slot 0).
+// Host-buffer entry points with large inputs: the upload (3.0 ms for the 128 MB of a 2^20-point G1 input from pageable
+// memory) is as long as the whole computation, so the two overlap -- and since round 3 the scalars go FIRST and are
+// decomposed and sorted ONCE, while the points (three quarters of the bytes) are still on their way in K chunks:
+//   1. all scalars up (32 n bytes), then decompose + sort of all 16 windows with the rows filed by chunk of the point
+//      index (k_local_sort_lds<true>: K sub-row bounds per key, common.hpp RowView)
+//   2. as each chunk of points lands: its base conversion, a work list over ITS sub-rows, the accumulation on top of the
+//      buckets the earlier chunks left (Phase::into), the merge of its split rows
+//   3. behind the last chunk: reduction, gather, D2H -- once.
+// Round 2 ran the whole front end per chunk (decompose and sort of the chunk's scalars four times over, ~0.15 ms each on
+// the GPU's critical path): 4.37 ms at 2^20 including the upload.  The accumulation of all chunks together (2.0 ms with
+// projective records) is about as long as the point upload (2.25 ms), so the call now ends one short chunk plus
+// reduction and tail behind the upload.  Returns with everything enqueued (slot 0).
 template <class CV>
-int run_chunked_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n) {
+int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n) {
   constexpr size_t PB = CV::RAW_WORDS * 4;  // bytes per wire point
-  uint64_t cut[10];  // chunk c = points [cut[c], cut[c + 1]): the first one upload_split_pct of n, the rest even
-  uint32_t K = 0;
-  cut[0] = 0;
-  for (uint32_t c = 1; c < ctx->upload_chunks; c++) {
+  // chunk c = points [cut[c], cut[c + 1]): the first one upload_split_pct of n (it should land when the sort is through),
+  // the last one half a share (only ITS accumulation trails the upload), the rest even; multiples of 64 points
+  ChunkCuts cuts;
+  {
+    const uint32_t want = std::min<uint32_t>(ctx->upload_chunks, MAX_UPLOAD_CHUNKS);
     const uint64_t first_end = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull);
-    const uint64_t b = c == 1 ? first_end : (first_end + (n - first_end) * (c - 1) / (ctx->upload_chunks - 1)) & ~63ull;
-    if (b > cut[K] && b < n) cut[++K] = b;  // no empty chunks (small n)
+    const double rest = (double)(n - std::min(n, first_end)), shares = want > 2 ? (double)(want - 2) + 0.5 : 1.0;
+    uint32_t K = 0;
+    cuts.cut[0] = 0;
+    double at = (double)first_end;
+    for (uint32_t c = 1; c < want; c++) {
+      const uint64_t bnd = c == 1 ? first_end : ((uint64_t)at) & ~63ull;
+      if (bnd > cuts.cut[K] && bnd < n) cuts.cut[++K] = (uint32_t)bnd;  // no empty chunks (small n)
+      at += rest / shares;
+    }
+    cuts.k = K + 1;
+    for (uint32_t j = cuts.k; j <= MAX_UPLOAD_CHUNKS; j++) cuts.cut[j] = (uint32_t)n;
   }
-  cut[++K] = n;
-  const size_t sc_stage = (size_t)ctx->cap * 96;
-  auto upload_chunk = [&](uint32_t c) -> int {
-    const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
-    int r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + first * 32, scalars + first * 32, cnt * 32, sc_stage + first * 32);
-    if (r == MSM377_OK) r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * PB, points + first * PB, cnt * PB, first * PB);
-    return r;
-  };
-  int rc = upload_chunk(0);
+  const uint32_t K = cuts.k;
+  if (K > 1 && !ctx->d_row_ptr_chunks) {  // K sub-row bounds per key: allocated the first time a call needs them
+    if (hipMalloc((void**)&ctx->d_row_ptr_chunks, (size_t)MSM377_NUM_WINDOWS * ((size_t)(NB + 1) * MAX_UPLOAD_CHUNKS + 1) * 4) != hipSuccess) {
+      ctx->d_row_ptr_chunks = nullptr;
+      (void)hipGetLastError();
+      ctx->err = "chunked upload: out of device memory for the row bounds";
+      return MSM377_ENOMEM;
+    }
+  }
+  int rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
   if (rc) return rc;
   int up_rc = MSM377_OK;
-  std::atomic<uint32_t> uploaded{1};  // chunks on the device so far
+  std::atomic<uint32_t> uploaded{0};  // chunks of points on the device so far
   std::atomic<bool> upload_done{false};
   std::thread upload([&] {
     if (hipSetDevice(ctx->device) != hipSuccess) up_rc = MSM377_EHIP;
-    for (uint32_t c = 1; c < K && up_rc == MSM377_OK; c++) {
-      up_rc = upload_chunk(c);
+    for (uint32_t c = 0; c < K && up_rc == MSM377_OK; c++) {
+      const uint64_t first = cuts.cut[c], cnt = cuts.cut[c + 1] - first;
+      up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * PB, points + first * PB, cnt * PB, first * PB);
       if (up_rc == MSM377_OK) uploaded.store(c + 1, std::memory_order_release);
     }
     upload_done.store(true, std::memory_order_release);
   });
+  {  // phase 1: decompose + sort, once
+    Phase ph;
+    ph.accumulate = false;
+    ph.back = false;
+    ph.cuts = cuts;
+    rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+  }
   for (uint32_t c = 0; c < K && rc == MSM377_OK; c++) {
     while (uploaded.load(std::memory_order_acquire) <= c && !upload_done.load(std::memory_order_acquire)) std::this_thread::yield();
     if (uploaded.load(std::memory_order_acquire) <= c) {  // the upload thread stopped on an error
       rc = up_rc ? up_rc : MSM377_EHIP;
       break;
     }
-    const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+    const uint64_t first = cuts.cut[c], cnt = cuts.cut[c + 1] - first;
     Phase ph;
-    ph.clear_err = c == 0;
+    ph.clear_err = false;
+    ph.sort = false;
     ph.into = c > 0;
     ph.back = c + 1 == K;
-    ph.base_first = first;
+    ph.cuts = cuts;
+    ph.chunk = c;
+    ph.chunk_points = cnt;
     rc = convert_bases<CV>(ctx, ctx->d_raw_points + first * CV::RAW_WORDS, cnt, first, c == 0);
-    if (rc == MSM377_OK) rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+    if (rc == MSM377_OK) rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
   }
   upload.join();
   if (rc) (void)hipStreamSynchronize(ctx->stream);
@@ -892,9 +937,9 @@ int g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
   const uint32_t* d_sc = ctx->d_raw_scalars;
   const uint32_t* d_pt = ctx->d_raw_points;
   int rc;
-  if (n >= ctx->upload_chunk_min && form != TABLE_XYZZ_GLV) {
+  if (n >= ctx->upload_chunk_min && form != TABLE_XYZZ_GLV && !ctx->capture) {  // (stage read-backs describe the plain row layout)
     const bool te = form == TABLE_TE;
-    rc = te ? run_chunked_upload<TeDev>(ctx, points, scalars, n) : run_chunked_upload<G1Dev>(ctx, points, scalars, n);
+    rc = te ? run_sorted_upload<TeDev>(ctx, points, scalars, n) : run_sorted_upload<G1Dev>(ctx, points, scalars, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     if (!(te && (ctx->h_err[0] & ERR_TE_ANY))) {
@@ -975,7 +1020,7 @@ int ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n >= ctx->upload_chunk_min) {  // chunks of points, like g1_msm: a chunk computes while the next one uploads
     ctx->bases_n = 0;
-    int rc = run_chunked_upload<EdDev>(ctx, points, scalars, n);
+    int rc = run_sorted_upload<EdDev>(ctx, points, scalars, n);
     if (rc) return rc;
     rc = finish_windows(ctx, 0);
     if (rc) return rc;
@@ -1002,11 +1047,12 @@ int ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d
 
 // The precomputed-window table and its wide-window work buffers (allocated on demand, 2.2-2.7 GB at 2^20 points).
 void free_table(msm377_ctx* ctx) {
-  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts})
+  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts, (void*)ctx->d_wide_temp})
     if (p) (void)hipFree(p);
   ctx->d_table = nullptr;
   ctx->d_wide_digits = nullptr;
   ctx->d_wide_counts = nullptr;
+  ctx->d_wide_temp = nullptr;
   ctx->table_cap = 0;
   ctx->table_windows = 0;
 }
@@ -1060,7 +1106,8 @@ int g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint6
     bool ok = hipMalloc((void**)&ctx->d_table, (size_t)windows * n * TeAffBase::REC_WORDS * 4) == hipSuccess;
     if (ok && wide)
       ok = hipMalloc((void**)&ctx->d_wide_digits, (size_t)WIDE_WINDOWS * n * 4) == hipSuccess &&
-           hipMalloc((void**)&ctx->d_wide_counts, ((size_t)MAX_SORT_BLOCKS + 1) * WIDE_NRANGE * 4) == hipSuccess;
+           hipMalloc((void**)&ctx->d_wide_temp, (size_t)WIDE_WINDOWS * n * sizeof(SortElem)) == hipSuccess &&
+           hipMalloc((void**)&ctx->d_wide_counts, ((size_t)MAX_SORT_BLOCKS * WP_R + (size_t)WP_R * WP_BCHUNKS * WP_R + WP_R + 1) * 4) == hipSuccess;
     if (!ok) {
       free_table(ctx);
       (void)hipGetLastError();
