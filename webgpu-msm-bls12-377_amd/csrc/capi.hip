@@ -48,30 +48,23 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (!ctx) return MSM377_ENOMEM;
   ctx->device = device;
   ctx->cap = max_points;
-  if (const char* e = getenv("MSM377_MERGE_QUAD")) ctx->merge_quad = atoi(e) != 0;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
-  if (const char* e = getenv("MSM377_H2D_THREADS")) ctx->h2d_threads = std::min(std::max(atoi(e), 1), 8);
+  if (const char* e = getenv("MSM377_UPLOAD_TRACE")) ctx->upload_trace_on = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 8);
   if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 5), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
-  if (const char* e = getenv("MSM377_KEY_SHIFT")) ctx->key_shift = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = std::min(std::max(atoi(e), 1), TailPool::WORKERS + 1);
   if (const char* e = getenv("MSM377_TAIL_WAIT_MS")) ctx->tail_pool.wait_limit_ns = (int64_t)std::max(atoi(e), 1) * 1000000ll;
   if (const char* e = getenv("MSM377_TAIL_SPIN_US")) ctx->tail_spin_us = atoll(e);
   if (const char* e = getenv("MSM377_TAIL_TRACE")) ctx->tail_trace = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_NUMA")) ctx->tail_pool.numa_local = atoi(e) != 0;
-  if (const char* e = getenv("MSM377_PIPELINE")) ctx->pipeline_parts = atoi(e) == 2 ? 2 : 1;
-  if (const char* e = getenv("MSM377_TE_AFFINE_TABLE")) ctx->te_affine_table = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TE_AFFINE_MSM")) ctx->te_affine_msm = atoi(e) != 0;
   if (const char* e = getenv("MSM377_NARROW_MAX")) ctx->narrow_max_points = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_PRECOMP_BITS")) ctx->precomp_bits = atoi(e) == (int)WIDE_BITS ? (int)WIDE_BITS : MSM377_WINDOW_BITS;
-  if (const char* e = getenv("MSM377_AFF_AFTER_SORT")) ctx->aff_down_after_sort = atoi(e);
   if (const char* e = getenv("MSM377_AFFINE_MIN")) ctx->affine_min_points = strtoull(e, nullptr, 10);
-  if (const char* e = getenv("MSM377_MERGE_FULL_GRID")) ctx->merge_full_grid = atoi(e) != 0;
   if (const char* e = getenv("MSM377_SEG_PLAIN")) ctx->seg_plain = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
   if (const char* e = getenv("MSM377_SEG_GLV")) ctx->seg_glv = std::min(std::max(atoi(e), (int)SEG_MIN), (int)SEG_MAX);
-  if (const char* e = getenv("MSM377_COOP_FROM")) ctx->coop_from = (uint32_t)atoi(e);
   if (const char* e = getenv("MSM377_ZERO_COPY_OUT")) ctx->zc_out = atoi(e);
   if (const char* e = getenv("MSM377_NARROW_SEG")) ctx->narrow_seg = (uint32_t)std::min(std::max(atoi(e), (int)NARROW_SEG), (int)SEG_BINS - 1);
   if (const char* e = getenv("MSM377_NARROW_QUAD_ITEMS")) ctx->narrow_quad_items = strtoull(e, nullptr, 10);
@@ -86,13 +79,9 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   int prio_least = 0, prio_greatest = 0;
   bool ok = hipSetDevice(device) == hipSuccess;
   if (ok && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
-  const bool use_prio = getenv("MSM377_STREAM_PRIORITY") ? atoi(getenv("MSM377_STREAM_PRIORITY")) != 0 : true;
-  ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, use_prio ? prio_greatest : prio_least) == hipSuccess &&
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
-            hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->part_fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->part_join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->acc_done, hipEventDisableTiming) == hipSuccess;
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
   dalloc((void**)&ctx->d_raw_points, cap * 96);
@@ -156,9 +145,8 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-  if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
-                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table, ctx->d_wide_digits, ctx->d_wide_counts, ctx->d_wide_temp, ctx->d_row_ptr_chunks};
+                  ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table, ctx->d_wide_digits, ctx->d_wide_counts, ctx->d_row_ptr_chunks};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
@@ -179,9 +167,7 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
       for (int p = 0; p < 2; p++)
         if (ctx->ev[p][s][k]) (void)hipEventDestroy(ctx->ev[p][s][k]);
   if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
-  for (hipEvent_t e : {ctx->part_fork, ctx->part_join, ctx->acc_done})
-    if (e) (void)hipEventDestroy(e);
-  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->acc_done) (void)hipEventDestroy(ctx->acc_done);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -24,7 +24,6 @@ constexpr uint32_t SEG_BINS = SEG_MAX + 1; // work items are counting-sorted by 
 constexpr int ERR_SCALAR = 1, ERR_GLV_RANGE = 2, ERR_NARROW_RANGE = 128;  // 128: a scalar's top digit does not fit the narrow-window path
 constexpr int ERR_TE_EXCEPTIONAL = MSM377_FB_ACCUMULATE, ERR_TE_MERGE = MSM377_FB_MERGE, ERR_TE_TREE = MSM377_FB_TREE, ERR_TE_CONVERT = MSM377_FB_CONVERT;
 constexpr int ERR_TE_ANY = ERR_TE_EXCEPTIONAL | ERR_TE_MERGE | ERR_TE_TREE | ERR_TE_CONVERT;
-constexpr uint32_t MERGE_GRID = 64;        // workgroups sweeping the list of split rows
 constexpr uint32_t NARROW_BITS = 11;       // digit width of the small-input path ...
 constexpr uint32_t NARROW_LOG = 11;        // ... whose windows have 2^11 buckets (the unsigned top digit needs the room: k_decompose_narrow)
 constexpr uint32_t NARROW_SEG = 8;         // entries per accumulation work item on that path
@@ -67,13 +66,9 @@ constexpr size_t SLOT_WORDS = (size_t)MAX_WINDOW_SLOTS * MSM377_G1_PARTIAL_POINT
 // ---- batched affine conversion (kernels/convert.hpp) ----
 // K = 4 (twice the waves, twice the host's share) measured the same; workgroups of 128 / 64 threads (smaller trees, 2 / 4 times
 // the host's share) stretch the conversion stage of a 2^20 MSM from 0.47 to 0.64 / 0.69 ms.
-#ifndef MSM377_AFF_K
-#define MSM377_AFF_K 8  // build-time A/B: tools/build_variant.sh
-#endif
-#ifndef MSM377_AFF_UNROLL
-#define MSM377_AFF_UNROLL 1
-#endif
-constexpr uint32_t AFF_THREADS = 256, AFF_K = MSM377_AFF_K, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
+// (Round 3, build-time A/B of the conversion alone, msm377_g1_set_bases_device wall time at 2^20: AFF_K = 8: 0.401 ms,
+// AFF_K = 4: 0.421, AFF_K = 8 with the point loops unrolled by 2: 0.408 -- gpurun_out/r03_conv.txt.)
+constexpr uint32_t AFF_THREADS = 256, AFF_K = 8, AFF_BLOCK_POINTS = AFF_THREADS * AFF_K;
 constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running product): 13 limbs each, 208 bytes per point
 inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POINTS - 1) / AFF_BLOCK_POINTS); }
 

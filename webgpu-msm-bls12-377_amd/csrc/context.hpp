@@ -3,8 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -17,6 +19,55 @@ using msm377::TailPool;
 using msm377::Fp64;
 using msm377::MAX_WINDOW_SLOTS;
 using msm377::NARROW_SEG;
+
+// MSM377_UPLOAD_TRACE=1: where the time of a host-buffer call goes (sequencer.hip run_sorted_upload).
+struct UploadTrace {
+  bool on = false;
+  uint32_t k = 0;
+  std::chrono::steady_clock::time_point t0;
+  std::vector<std::pair<const char*, double>> marks;
+  double up_us[9] = {}, enq_us[9] = {};
+  hipEvent_t ev[12] = {};
+  uint32_t nev = 0;
+  double now_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+  void begin(bool enabled, uint32_t chunks) {
+    on = enabled;
+    if (!on) return;
+    k = chunks;
+    nev = 0;
+    marks.clear();
+    t0 = std::chrono::steady_clock::now();
+    for (hipEvent_t& e : ev)
+      if (!e) (void)hipEventCreate(&e);
+  }
+  void host(const char* what) {
+    if (on) marks.emplace_back(what, now_us());
+  }
+  void chunk_up(uint32_t c) {
+    if (on) up_us[c] = now_us();
+  }
+  void chunk_enqueued(uint32_t c) {
+    if (on) enq_us[c] = now_us();
+  }
+  void gpu(hipStream_t st, uint32_t slot) {  // slot 0: before the sort; 1: behind it; 2 + c: behind chunk c's phase
+    if (on && slot < 12) {
+      (void)hipEventRecord(ev[slot], st);
+      if (slot + 1 > nev) nev = slot + 1;
+    }
+  }
+  void report() {  // after the call's completion event
+    if (!on) return;
+    fprintf(stderr, "upload trace (us after the call; GPU times relative to the sort's launch):");
+    for (auto& m : marks) fprintf(stderr, "  %s %.0f", m.first, m.second);
+    for (uint32_t c = 0; c < k; c++) fprintf(stderr, "  chunk %u up %.0f enq %.0f", c, up_us[c], enq_us[c]);
+    for (uint32_t s = 1; s < nev; s++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[0], ev[s]) == hipSuccess) fprintf(stderr, "  gpu[%s%u] +%.0f", s == 1 ? "sort" : "chunk ", s == 1 ? 0u : s - 2, ms * 1e3);
+    }
+    fprintf(stderr, "  done %.0f\n", now_us());
+    (void)hipGetLastError();
+  }
+};
 
 struct msm377_ctx {
   int device = 0;
@@ -49,8 +100,7 @@ struct msm377_ctx {
   uint32_t table_windows = 0;         // windows the allocated table holds (16, or WIDE_WINDOWS)
   int precomp_bits = MSM377_WINDOW_BITS;  // window width msm377_g1_set_bases_precomputed builds its next table for: 16 or 20 (msm377_ctx_set_precompute_window, MSM377_PRECOMP_BITS)
   uint32_t* d_wide_digits = nullptr;  // wide windows: 13 x n u32 biased 20-bit digits, the flat list the sort reads
-  SortElem* d_wide_temp = nullptr;    // wide windows: the elements between the two partition passes (pass A writes d_sort_temp, pass B this)
-  uint32_t* d_wide_counts = nullptr;  // wide windows: the two passes' per-workgroup stream counts / offsets and the coarse region bounds
+  uint32_t* d_wide_counts = nullptr;  // wide windows: MAX_SORT_BLOCKS x 4096 per-chunk range counts, then 4096 range totals
   uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
   uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
   uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
@@ -61,7 +111,6 @@ struct msm377_ctx {
   hipEvent_t aff_up_done = nullptr;
   hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
   uint32_t table_window_bits = MSM377_WINDOW_BITS;  // doublings between two windows of a precomputed table (AffDoublingSource)
-  int aff_down_after_sort = 0;        // MSM377_AFF_AFTER_SORT=1: k_affine_down waits for the sort (see affine_convert_finish)
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
   bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
   // Below this the batched conversion does not pay: it costs ~9 more products per point than the projective record and
@@ -77,7 +126,6 @@ struct msm377_ctx {
   // host-buffer entry points: pinned staging + copy workers (allocated on first use)
   uint8_t* h_stage = nullptr;  // cap x 128 bytes
   hipStream_t copy_stream[8] = {};
-  int h2d_threads = 4;                // copy workers of the host-buffer entry points (MSM377_H2D_THREADS, 1..8)
   // state
   uint64_t bases_n = 0;  // resident base count (fixed-base mode)
   uint64_t last_n = 0;
@@ -93,10 +141,9 @@ struct msm377_ctx {
   uint32_t* dm_partials = nullptr;  // device address of h_partials
   uint32_t* d_out_count = nullptr;
   int timing = 0;  // msm377_ctx_set_timing: 0 off, 1 every stage, 2 the accumulation kernel only
-  // First reduction level run with one addition per lane quad.  0 = automatic: the first level whose 4 lanes x additions
-  // x windows fit one wave per SIMD (65536 lanes) -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from
-  // there on, slower before), 6 for 8, 4 for the 2 windows a rank of an 8-GPU run owns.  MSM377_COOP_FROM forces it (15 = never).
-  uint32_t coop_from = 0;
+  // First reduction level run with one addition per lane quad: the first level whose 4 lanes x additions x windows fit
+  // coop_threads -- level 7 for 16 windows (measured: 18-24 -> 13-18 us per level from there on, slower before), 6 for 8, 4
+  // for the 2 windows a rank of an 8-GPU window-sharded run owns.
   // MSM377_COOP_THREADS: a tree level runs one lane quad per addition once that takes at most this many threads.  65536 / 131072 /
   // 262144 make no difference on the main path (2^20: 2.74 ms each); on the narrow path 131072 moves its levels 0-2 to quads.
   uint32_t coop_threads = 131072;
@@ -114,20 +161,17 @@ struct msm377_ctx {
   // 2^19 2.08 / 2.00, 2^20 3.56 / 3.51, 2^22 12.56 / 12.39 (halved bucket reduction and host tail).
   int glv_mode = 0;
   int bases_form = 0;      // TableForm of the resident base table (fixed-base mode)
-  bool te_affine_table = true;  // MSM377_TE_AFFINE_TABLE=0: resident Edwards tables stay projective (A/B knob)
   int g1_form = 1;         // G1 full-MSM entry points: 1 = twisted Edwards form (te377.hpp, default), 0 = Weierstrass XYZZ (MSM377_G1_FORM)
   bool last_glv = false;
-  bool merge_full_grid = true;  // MSM377_MERGE_FULL_GRID=0: fixed 64-workgroup sweep of the split-row list (A/B knob)
-  bool merge_quad = true;  // MSM377_MERGE_QUAD=0: thread-per-row merge of split rows
   uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
   hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
-  hipStream_t stream3 = nullptr;      // second part of a pipelined call (enqueue_windows)
-  hipEvent_t part_fork = nullptr, part_join = nullptr, acc_done = nullptr;
+  hipEvent_t acc_done = nullptr;      // recorded behind the accumulation kernel (TailArm: the host arms the tail workers then)
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
+  UploadTrace upload_trace;
+  bool upload_trace_on = false;           // MSM377_UPLOAD_TRACE=1
   uint32_t upload_chunks = 5;              // chunks of the points in the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..8)
   uint32_t upload_split_pct = 16;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 5..90): it should land when the sort of the scalars is through
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
-  bool key_shift = true;              // MSM377_KEY_SHIFT=0: full-width key ranges in every window (A/B knob)
   TailPool tail_pool;
   int tail_threads = 6;               // MSM377_TAIL_THREADS: threads of the host tail (1..8, tail_horner_mt)
   // MSM377_TAIL_SPIN_US: how long at most the tail workers poll for their job after a call has armed them (TailPool;
@@ -136,8 +180,6 @@ struct msm377_ctx {
   // exceptional-case flags shared a cache line then and the threads fought over it -- TeChecked is padded now.)
   int64_t tail_spin_us = 1000;
   bool tail_trace = false;  // MSM377_TAIL_TRACE=1
-  int pipeline_parts = 1;             // MSM377_PIPELINE=2: two parts on two streams.  Measured: no gain at 2^20 / 2^21 (3.19 vs 3.17 ms), 2 % at 2^22 -- the accumulation kernel owns every VGPR of the chip, so kernels of the other part cannot become co-resident
-  uint32_t last_parts = 1;
   double stage_ms[MSM377_NUM_STAGES] = {};
   int last_products = 0;        // field products per bucket addition of the last accumulation launch (bench.py's int32-mad roof)
   // Inputs of at most this many points run the narrow-window path (11-bit windows: 23 x 2048 buckets instead of

@@ -1,5 +1,5 @@
 // Stage 3: bucket accumulation -- work list (k_work_hist / scan / scatter), k_accumulate (the dominant kernel),
-// k_accumulate_quad (small inputs), k_merge_split_rows[_quad].  Replaces wgsl/cuzk/smvp_bls12_377.template.wgsl:72-160.
+// k_accumulate_quad (small inputs), k_merge_split_rows_quad.  Replaces wgsl/cuzk/smvp_bls12_377.template.wgsl:72-160.
 // Device code; included by sequencer.hip only.
 #pragma once
 #include "../curves.hpp"
@@ -199,31 +199,6 @@ __global__ void __launch_bounds__(256, OCC) k_accumulate(const uint32_t* __restr
     store_bucket<CV>(buckets, L, ws, t, acc);
   } else {
     store_record<CV>(ovf + (size_t)(row_ovf_base[it.row] + it.seg - 1) * CV::BKT_WORDS, acc);
-  }
-}
-
-// Thread per split row: bucket += its overflow partials (serial; 3 additions per row of the
-// top window at n = 2^20, more only under heavy skew).
-template <class CV>
-__global__ void __launch_bounds__(256, 2) k_merge_split_rows(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
-                                                             const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
-                                                             const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                             int* __restrict__ err, uint32_t L, RowView rv) {
-  const uint32_t count = counters[0];
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
-    const uint32_t row = split_rows[i];
-    const uint32_t len = row_len(row_ptr, L, row, rv);
-    const uint32_t nseg = row_split(len, SEG).nseg;
-    const uint32_t ws = row >> L, t = row & ((1u << L) - 1);
-    typename CV::Pt acc = load_bucket<CV>(buckets, L, ws, t);
-    const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::BKT_WORDS;
-    bool bad = false;
-    for (uint32_t s = 1; s < nseg; s++) {
-      acc = CV::add(acc, load_record<CV>(src + (size_t)(s - 1) * CV::BKT_WORDS));
-      bad |= CV::is_bad(acc);
-    }
-    if (bad) atomicOr(err, ERR_TE_MERGE);
-    store_bucket<CV>(buckets, L, ws, t, acc);
   }
 }
 

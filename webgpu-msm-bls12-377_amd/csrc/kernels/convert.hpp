@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
   const uint64_t base = (uint64_t)blk * AFF_BLOCK_POINTS + tid;
   bool bad = false;
   Fp::El c = Fp::one();
-#pragma unroll MSM377_AFF_UNROLL
+#pragma unroll 1
   for (uint32_t j = 0; j < AFF_K; j++) {
     const uint64_t i = base + (uint64_t)j * AFF_THREADS;
     if (i >= n) break;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, cons
   __syncthreads();
   Fp::El inv = get13(tree[AFF_THREADS + tid]);  // 1 / (the product of this thread's Z's)
   const uint64_t base = (uint64_t)blk * AFF_BLOCK_POINTS + tid;
-#pragma unroll MSM377_AFF_UNROLL
+#pragma unroll 1
   for (int j = (int)AFF_K - 1; j >= 0; j--) {
     const uint64_t i = base + (uint64_t)j * AFF_THREADS;
     if (i >= n) continue;

@@ -79,8 +79,11 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ 
 // c = 11 the top window starts at bit 242, so scalars below r (253 bits) leave it digits below 1 195 < 2^L = 2 048;
 // a larger top digit (scalars >= 2^253) raises ERR_NARROW_RANGE and the call reruns on the 16-bit path.  All digits
 // are stored biased by 2^L: d + 2^L in [0, 2^(L+1)).
-// The error condition stays the reference's (cuzk/utils.ts:95-98 throws when the 16-bit recode ends with a carry):
-// the same inputs are rejected whichever window width runs.
+// The error condition is the one of the 16-bit recode for every input size (cuzk/utils.ts:95-98 throws when the recode
+// ends with a carry; with 16-bit windows that is k >= 2^255 - 2^239), whichever window width runs here.  The reference
+// itself switches to 4-bit windows below 65 536 points (submission.ts:97), where the same check fires for every
+// k > 0x7777...7 -- a set that differs only in NON-canonical scalars (every k < r passes both): deliberately not
+// reproduced, one error condition for all sizes (tests/test_g1_parity_gpu.py::test_narrow_windows_edge_cases).
 __global__ void __launch_bounds__(256) k_decompose_narrow(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n, uint32_t c,
                                                           uint32_t L, uint32_t W, int* __restrict__ err) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;

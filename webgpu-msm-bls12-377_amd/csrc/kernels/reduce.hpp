@@ -200,6 +200,12 @@ __device__ __forceinline__ void pack_partial(const uint32_t* __restrict__ bucket
 }
 // The block that finishes last (a device-memory counter) hands the call over to the host: error word, then the sequence
 // number the host is polling for (wait_zero_copy_out).  Call with every store of the block issued; all threads.
+// INVARIANT: the host returns to its caller the moment it sees the sequence number -- while this kernel is still
+// finishing (the counter reset below, the grid's last waves) and before the stream's completion event fires.  So
+// nothing in or behind this kernel may touch a buffer that the host or another stream reuses for the next call: it reads
+// the buckets and writes the partial records, the error word and its own counter, all of which the next call touches
+// only in main-stream order, and it must stay the last launch of a call.  (The next call's base conversion rewrites
+// d_bases from the side stream without waiting for the main stream -- fine only because of this.)
 __device__ __forceinline__ void publish_to_host(uint32_t blocks, uint32_t* host_flag, uint32_t* dev_count, const int* d_err, uint32_t seq) {
   __threadfence_system();
   __syncthreads();

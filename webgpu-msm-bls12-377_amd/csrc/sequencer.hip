@@ -71,7 +71,7 @@ void note_fallback(msm377_ctx* ctx, uint32_t mask) {
 // 3.3 + 2.9 ms for hipHostRegister + copy.  Returns when the data is on the device.
 int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, size_t stage_off) {
   constexpr int NT_MAX = 8;
-  const int NT = ctx->h2d_threads;
+  constexpr int NT = 4;  // copy workers: 2, 4, 6 or 8 all moved 128 MB in 2.9-3.0 ms (round 2) -- the DMA sets the pace
   constexpr size_t SMALL = 8u << 20, PIECE = 4u << 20;
   if (bytes < SMALL) {  // not worth four threads
     HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
@@ -138,8 +138,10 @@ template <class CV>
 int convert_bases(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, uint64_t first = 0, bool clear_err = true) {
   // Runs on the side stream: it depends on the points only, while decomposition and the sort
   // depend on the scalars only, so the two overlap (HBM-bound vs LDS/latency-bound);
-  // k_accumulate waits for `bases_ready`.  Every entry point ends with a host-side wait for the
-  // main stream, so the previous call's readers of d_bases are done.
+  // k_accumulate waits for `bases_ready`.  The previous call's readers of d_bases are done: every entry point ends with
+  // a host-side wait -- for the main stream's completion event, or (zero-copy output) for the sequence number that the
+  // gather kernel publishes, and that kernel is the LAST launch of a call and reads the buckets only (the invariant
+  // is spelled out at publish_to_host, kernels/reduce.hpp).
   if (n == 0) return MSM377_OK;
   if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][0], ctx->stream2);
   if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
@@ -196,12 +198,8 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
     const int inv_rc = invert_block_products_mt(ctx, 0, nblk);
     if (inv_rc) return inv_rc;
   }
-  // k_affine_down beside k_local_sort: each stretches the other (they fight over the memory system), and when the way
-  // down was first built letting it wait for the sort was the faster order.  At the end of round 2 -- shorter front
-  // end, zero-copy products, polled flag -- the interleaved A/B says the opposite: 2^20 2.62 -> 2.59 ms, 2^21 5.08 ->
-  // 5.02, 2^22 10.39 -> 10.21 without the wait (two contexts each way), so the way down starts as soon as the host
-  // has inverted the block products.  MSM377_AFF_AFTER_SORT=1 restores the wait.
-  if (behind_sort && ctx->aff_down_after_sort) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->sort_done, 0));
+  // The way down starts as soon as the host has inverted the block products, beside whatever the sort is doing (letting
+  // it wait for the sort was measured both ways in round 2: 2^20 2.62 -> 2.59 ms, 2^22 10.39 -> 10.21 without the wait).
   hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
@@ -223,7 +221,6 @@ uint32_t auto_seg(const msm377_ctx* ctx, uint64_t entries, bool glv) {
   return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, SEG_MIN), SEG_MAX);
 }
 
-constexpr uint64_t PIPELINE_MIN_ENTRIES = 1ull << 21;  // (windows x points) below which a call stays in one part
 
 
 // Enqueue stages decompose .. gather for windows [wb, wb + wc) against ctx->d_bases, the D2H of
@@ -302,7 +299,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // One memset clears this part's work-list counters AND its key_max words (0 = full-width ranges); k_decompose
   // then measures window 15 of the plain front end.
   hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, meta_block, META_BLOCK_WORDS, (uint32_t*)d_err, (ph.clear_err && part == 0) ? 1u : 0u);
-  uint32_t* top_key_max = (ctx->key_shift && !glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
+  uint32_t* top_key_max = (!glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
   const uint64_t max_items = (uint64_t)wc * NB + entries / SEG;  // every row has an item; extra ones are full segments
   // a lane quad per work item while the launch is one chain's latency (up to 2^14 points: ~94 k items); beyond that
   // the quads are VALU-bound like threads and only add their exchange instructions (kernel at 2^16: 0.216 / 0.183 ms)
@@ -325,27 +322,25 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
   }
 
-  if (wide) {  // one counting sort of the 13 n entries by key: two radix-64 passes (kernels/wide.hpp), then k_local_sort_lds per range
+  if (wide) {  // one counting sort of the 13 n entries by key: 4096 ranges, then k_local_sort_lds per range
+    // (Two radix-64 passes with the tile-staged scatter of the main path instead of one pass into 4096 streams: sort stage
+    // 0.33 -> 0.62 ms at 2^20.  The top window's 13-bit digits put a twelfth of all entries into ONE coarse region, whose
+    // four workgroups then ran six times longer than the rest; with that evened out the two passes still cost what the
+    // one pass costs, profiles/r03_final/wide_two_pass_dropped.txt.)
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
     const uint64_t N = entries;
     uint32_t chunks = MAX_SORT_BLOCKS;
     const uint64_t want = (N + 8191) / 8192;
     if (chunks > want) chunks = (uint32_t)(want ? want : 1);
-    const uint64_t per_chunk = ((N + chunks - 1) / chunks + 7) & ~7ull;  // whole 16-byte groups of digits
-    uint32_t* countsA = ctx->d_wide_counts;                                   // [chunks][64]
-    uint32_t* countsB = countsA + (size_t)MAX_SORT_BLOCKS * WP_R;             // [64 regions][WP_BCHUNKS][64]
-    uint32_t* regionA = countsB + (size_t)WP_R * WP_BCHUNKS * WP_R;           // 65 bounds of the coarse regions
-    SortElem* tempB = ctx->d_wide_temp;
-    const WideFromDigits srcA{ctx->d_wide_digits, (uint32_t)n, (uint32_t)ph.table_stride};
-    const WideFromElems srcB{sort_temp};
-    hipLaunchKernelGGL(k_wide_count<WideFromDigits>, dim3(chunks, 1), dim3(1024), 0, st, srcA, (const uint32_t*)nullptr, countsA, N, per_chunk);
-    hipLaunchKernelGGL(k_wide_scan_a, dim3(1), dim3(1024), 0, st, countsA, regionA, chunks);
-    hipLaunchKernelGGL(k_wide_scatter<WideFromDigits>, dim3(chunks, 1), dim3(1024), 0, st, srcA, (const uint32_t*)nullptr, (const uint32_t*)countsA, sort_temp, N, per_chunk);
-    hipLaunchKernelGGL(k_wide_count<WideFromElems>, dim3(WP_BCHUNKS, WP_R), dim3(1024), 0, st, srcB, (const uint32_t*)regionA, countsB, N, per_chunk);
-    hipLaunchKernelGGL(k_wide_scan_b, dim3(WP_R), dim3(WP_R), 0, st, countsB, (const uint32_t*)regionA, region_base);
-    hipLaunchKernelGGL(k_wide_scatter<WideFromElems>, dim3(WP_BCHUNKS, WP_R), dim3(1024), 0, st, srcB, (const uint32_t*)regionA, (const uint32_t*)countsB, tempB, N, per_chunk);
-    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, (const SortElem*)tempB, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr,
-                       WIDE_NRANGE, NB, ChunkCuts{});
+    const uint64_t per_chunk = ((N + chunks - 1) / chunks + 3) & ~3ull;  // whole 16-byte groups of digits
+    uint32_t* counts = ctx->d_wide_counts;
+    uint32_t* tot = counts + (size_t)MAX_SORT_BLOCKS * WIDE_NRANGE;
+    hipLaunchKernelGGL(k_wide_count, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, N, per_chunk);
+    hipLaunchKernelGGL(k_wide_total, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, tot, chunks);
+    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, tot, region_base);
+    hipLaunchKernelGGL(k_wide_offsets, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, region_base, chunks);
+    hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk, (uint32_t)n, (uint32_t)ph.table_stride);
+    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB, ChunkCuts{});
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   } else if (narrow) {
@@ -394,9 +389,6 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
       if (hook_rc) return hook_rc;
     }
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->bases_ready, 0));
-    // The accumulation launches of the two parts run one after the other (the second waits for the first): they
-    // are the power-limited kernels, sharing the GPU would only stretch both.
-    if (part == 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->acc_done, 0));
     ctx->last_products = BP::MADD_PRODUCTS;
     {
       StageTimer tk(ctx, MSM377_STAGE_ACC_KERNEL, st, part);
@@ -419,17 +411,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     }
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
-    bool merged = false;
-    if constexpr (CV::HAS_QUAD) {
-      if (ctx->merge_quad) {
-        hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(ctx->merge_full_grid ? (rows + 63) / 64 : 4 * MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
-                           row_ovf_base, ovf, SEG, d_err, L, rv);
-        merged = true;
-      }
-    }
-    if (!merged)
-      hipLaunchKernelGGL(k_merge_split_rows<CV>, dim3(ctx->merge_full_grid ? (rows + 255) / 256 : MERGE_GRID), dim3(256), 0, st, row_ptr, buckets, counters, split_rows,
-                         row_ovf_base, ovf, SEG, d_err, L, rv);
+    static_assert(CV::HAS_QUAD, "every curve policy has the quad-cooperative addition");
+    hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3((rows + 63) / 64), dim3(256), 0, st, row_ptr, buckets, counters, split_rows, row_ovf_base, ovf, SEG, d_err, L, rv);
     HIP_TRY(ctx, hipGetLastError());
   }  // ph.accumulate
   }  // ph.front
@@ -450,9 +433,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     }
     const uint32_t levels = L;  // log2 of the buckets per window
     const uint32_t first_level = 0;
-    uint32_t coop_from = ctx->coop_from;
-    if (coop_from == 0)
-      for (coop_from = 0; coop_from < levels && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > ctx->coop_threads; coop_from++) {
+    uint32_t coop_from = 0;
+    for (coop_from = 0; coop_from < levels && 4ull * (coop_from + 1) * (NB >> (coop_from + 1)) * wc > ctx->coop_threads; coop_from++) {
       }
     // Levels [0, coop_from): one thread per addition (VALU-bound: 2^18 additions per level at first); [coop_from,
     // tail_from): one lane quad per addition, one launch per level; [tail_from, levels): k_reduce_tail, one launch.
@@ -500,10 +482,10 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
 // the partial records into slot `slot` of ctx->h_partials and that slot's completion event.
 // Nothing here waits for the GPU.
 //
-// Large calls run as TWO parts (half the windows each) on two streams: while the power-limited accumulation
-// kernel of part 0 runs, the GPU also sorts part 1's digit columns and builds its work list (LDS / latency
-// bound), and part 0's merge and bucket reduction (short launches, latency bound from level 5 on) overlap
-// part 1's accumulation.  Only the second part's reduction stays exposed.
+// (Rounds 1 and 2 could run a large call as TWO parts of half the windows on two streams, so that one part's sort and
+// reduction hid under the other's accumulation: 3.19 vs 3.17 ms at 2^20, then 2.72 -> 2.89 on round 2's kernels -- the
+// accumulation kernel owns every VGPR of the chip, kernels of another stream do not become co-resident.  Removed in
+// round 3; PartView keeps the stream and the window slots of a call together.)
 template <class CV, class BP = CV>
 int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars, uint32_t wb, uint32_t wc, int slot, bool glv = false,
                     const Phase& ph = Phase()) {
@@ -512,34 +494,20 @@ int enqueue_windows(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scala
   hipStream_t st = ctx->stream;
   int* d_err = ctx->d_err + slot;
   uint32_t* d_partials = ctx->d_partials + (size_t)slot * SLOT_WORDS;
-  const bool whole = ph.front && ph.back;  // the two-stream pipeline only for calls enqueued in one piece
-  const uint32_t parts = (whole && ctx->pipeline_parts == 2 && wc >= 2 && !ctx->capture && !ph.table && (uint64_t)wc * n >= PIPELINE_MIN_ENTRIES) ? 2u : 1u;
-  // the error word is cleared by part 0's first kernel together with its counters -- unless there is no such kernel
-  // (back phase only) or a second part on another stream could raise a bit before that kernel has run
-  const bool clear_here = ph.clear_err && (!ph.front || parts == 2);
+  // the error word is cleared by the call's first kernel together with its counters -- unless there is no such kernel
+  // (back phase only)
+  const bool clear_here = ph.clear_err && !ph.front;
   if (clear_here) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, (uint32_t*)d_err, 1u, (uint32_t*)nullptr, 0u);
   Phase part_phase = ph;
   part_phase.clear_err = ph.clear_err && !clear_here;
-  PartView pv[2];
-  const uint32_t wc0 = parts == 2 ? (wc + 1) / 2 : wc;
-  pv[0] = PartView{st, 0, 0, wb, wc0, 0, 0};
-  pv[1] = PartView{ctx->stream3, 1, wc0, wb + wc0, wc - wc0, (size_t)wc0 * NB + (size_t)wc0 * n / SEG_MIN + 1, (size_t)wc0 * n / SEG_MIN + 1};
-  if (parts == 2) {
-    HIP_TRY(ctx, hipEventRecord(ctx->part_fork, st));  // after the error word is cleared and everything queued before this call
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->part_fork, 0));
-  }
-  ctx->last_parts = parts;
-  ctx->zc_active = ph.zc_out && ph.back && ctx->zc_out && parts == 1 && slot == 0 && !ph.table;
+  const PartView pv{st, 0, 0, wb, wc, 0, 0};
+  ctx->zc_active = ph.zc_out && ph.back && ctx->zc_out && slot == 0 && !ph.table;
   if (ctx->zc_active) ctx->out_seq++;
-  for (uint32_t p = 0; p < parts; p++) {
-    int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv[p], d_err, d_partials, glv, parts == 2 ? MAX_SORT_BLOCKS / 2 : MAX_SORT_BLOCKS, part_phase);
+  {
+    const int rc = enqueue_part<CV, BP>(ctx, d_scalars, n_scalars, n, pv, d_err, d_partials, glv, MAX_SORT_BLOCKS, part_phase);
     if (rc) return rc;
   }
   if (!ph.back) return MSM377_OK;
-  if (parts == 2) {
-    HIP_TRY(ctx, hipEventRecord(ctx->part_join, ctx->stream3));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->part_join, 0));
-  }
   const uint32_t wc_out = ph.table ? 1u : wc;  // precomputed-window tables fold the windows on the GPU
   const uint32_t pp_out = ph.wide ? WIDE_POINTS : (uint32_t)MSM377_G1_PARTIAL_POINTS;
   if (!ctx->zc_active) {
@@ -592,7 +560,7 @@ int finish_windows(msm377_ctx* ctx, int slot) {
         continue;
       }
       double sum = 0.0;  // a pipelined call reports the sum over its two parts (they overlap each other in wall time)
-      for (uint32_t p = 0; p < (s == MSM377_STAGE_CONVERT ? 1u : ctx->last_parts); p++) {
+      for (uint32_t p = 0; p < 1u; p++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev[p][s][0], ctx->ev[p][s][1]) == hipSuccess) sum += ms;
       }
@@ -819,8 +787,13 @@ int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sca
       return MSM377_ENOMEM;
     }
   }
+  // MSM377_UPLOAD_TRACE=1: host timestamps (us after the call) of the upload and enqueue steps and GPU timestamps of the
+  // phases' ends (HIP events on the main stream), printed by upload_trace_report once the call is through.
+  UploadTrace& tr = ctx->upload_trace;
+  tr.begin(ctx->upload_trace_on, K);
   int rc = h2d_staged(ctx, ctx->d_raw_scalars, scalars, n * 32, (size_t)ctx->cap * 96);
   if (rc) return rc;
+  tr.host("scalars up");
   int up_rc = MSM377_OK;
   std::atomic<uint32_t> uploaded{0};  // chunks of points on the device so far
   std::atomic<bool> upload_done{false};
@@ -829,6 +802,7 @@ int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sca
     for (uint32_t c = 0; c < K && up_rc == MSM377_OK; c++) {
       const uint64_t first = cuts.cut[c], cnt = cuts.cut[c + 1] - first;
       up_rc = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * PB, points + first * PB, cnt * PB, first * PB);
+      tr.chunk_up(c);
       if (up_rc == MSM377_OK) uploaded.store(c + 1, std::memory_order_release);
     }
     upload_done.store(true, std::memory_order_release);
@@ -838,7 +812,10 @@ int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sca
     ph.accumulate = false;
     ph.back = false;
     ph.cuts = cuts;
+    tr.gpu(ctx->stream, 0);
     rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+    tr.gpu(ctx->stream, 1);
+    tr.host("sort enqueued");
   }
   for (uint32_t c = 0; c < K && rc == MSM377_OK; c++) {
     while (uploaded.load(std::memory_order_acquire) <= c && !upload_done.load(std::memory_order_acquire)) std::this_thread::yield();
@@ -857,6 +834,8 @@ int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sca
     ph.chunk_points = cnt;
     rc = convert_bases<CV>(ctx, ctx->d_raw_points + first * CV::RAW_WORDS, cnt, first, c == 0);
     if (rc == MSM377_OK) rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+    tr.gpu(ctx->stream, 2 + c);
+    tr.chunk_enqueued(c);
   }
   upload.join();
   if (rc) (void)hipStreamSynchronize(ctx->stream);
@@ -942,6 +921,7 @@ int g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
     rc = te ? run_sorted_upload<TeDev>(ctx, points, scalars, n) : run_sorted_upload<G1Dev>(ctx, points, scalars, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    ctx->upload_trace.report();
     if (!(te && (ctx->h_err[0] & ERR_TE_ANY))) {
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
@@ -1047,12 +1027,11 @@ int ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d
 
 // The precomputed-window table and its wide-window work buffers (allocated on demand, 2.2-2.7 GB at 2^20 points).
 void free_table(msm377_ctx* ctx) {
-  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts, (void*)ctx->d_wide_temp})
+  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts})
     if (p) (void)hipFree(p);
   ctx->d_table = nullptr;
   ctx->d_wide_digits = nullptr;
   ctx->d_wide_counts = nullptr;
-  ctx->d_wide_temp = nullptr;
   ctx->table_cap = 0;
   ctx->table_windows = 0;
 }
@@ -1062,7 +1041,7 @@ int g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n) {
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int form = pick_form(ctx, n);
-  if (form == TABLE_TE && ctx->te_affine_table) form = TABLE_TE_AFFINE;  // resident: one inversion per point, once
+  if (form == TABLE_TE) form = TABLE_TE_AFFINE;  // resident: affine records by the batched inversion, once
   rc = convert_table(ctx, (const uint32_t*)d_points, n, form);
   if (rc) return rc;
   // raw copy for the (never expected) fallback from the Edwards form: see resident_table_to_weierstrass
@@ -1106,8 +1085,7 @@ int g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint6
     bool ok = hipMalloc((void**)&ctx->d_table, (size_t)windows * n * TeAffBase::REC_WORDS * 4) == hipSuccess;
     if (ok && wide)
       ok = hipMalloc((void**)&ctx->d_wide_digits, (size_t)WIDE_WINDOWS * n * 4) == hipSuccess &&
-           hipMalloc((void**)&ctx->d_wide_temp, (size_t)WIDE_WINDOWS * n * sizeof(SortElem)) == hipSuccess &&
-           hipMalloc((void**)&ctx->d_wide_counts, ((size_t)MAX_SORT_BLOCKS * WP_R + (size_t)WP_R * WP_BCHUNKS * WP_R + WP_R + 1) * 4) == hipSuccess;
+           hipMalloc((void**)&ctx->d_wide_counts, ((size_t)MAX_SORT_BLOCKS + 1) * WIDE_NRANGE * 4) == hipSuccess;
     if (!ok) {
       free_table(ctx);
       (void)hipGetLastError();
