@@ -682,12 +682,22 @@ def test_alternative_settings_of_the_default_path(oracle, monkeypatch, knobs):
         eng.close()
 
 
-def test_host_buffers_upload_in_two_chunks(oracle, monkeypatch):
-    """msm377_g1_msm with large host buffers uploads and accumulates in two chunks of points (chunk B on top of chunk
-    A's buckets, one reduction): forced here at small sizes through MSM377_UPLOAD_CHUNK_MIN; both coordinate forms,
-    ragged sizes, skew, and an exceptional point in the second chunk (whole call reruns on the Weierstrass path)."""
+@pytest.mark.parametrize("schedule", ["front end per chunk", "sorted once", "sorted once, 7 chunks"])
+def test_host_buffers_upload_in_chunks(oracle, monkeypatch, schedule):
+    """msm377_g1_msm with large host buffers uploads and accumulates in chunks of points (later chunks on top of the
+    earlier ones' buckets, one reduction): forced here at small sizes through MSM377_UPLOAD_CHUNK_MIN; both schedules
+    (the default: every chunk its own decompose / sort; MSM377_UPLOAD_SORT_ONCE: scalars first, one sort with the rows
+    filed by chunk, every chunk its own sub-rows), both coordinate forms, ragged sizes, skew, and an exceptional point
+    in a later chunk (whole call reruns on the Weierstrass path)."""
     monkeypatch.setenv("MSM377_UPLOAD_CHUNK_MIN", "100")
+    if schedule != "front end per chunk":
+        monkeypatch.setenv("MSM377_UPLOAD_SORT_ONCE", "1")
+    if schedule.endswith("7 chunks"):
+        monkeypatch.setenv("MSM377_UPLOAD_CHUNKS", "7")
+        monkeypatch.setenv("MSM377_UPLOAD_SPLIT", "9")
     eng = msm.MsmEngine(1 << 17)
+    eng.reserve_host_staging()
+    eng.reserve_host_staging()  # idempotent
     try:
         for n in (128, 131, 1000, 4097, 70001):
             pts, ks = seeded_inputs(oracle, n, 600 + n)

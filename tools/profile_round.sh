@@ -1,6 +1,7 @@
 #!/bin/bash
 # One gpurun call -> everything profiles/<tag>/ needs (run from the repo root ON THE GPU BOX):
 #   bench.json               python bench.py   (default steps / warm-up, free-running clocks, with the CPU baseline)
+#   bench_ed / bench_fixed64 / bench_fixed64_wide / bench_driver_flags / bench_r01_protocol .json   the side workloads and protocols
 #   kernel_stats.csv         rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --no-cpu-baseline`
 #   bench_under_rocprof.log  the bench line printed inside that profiled run (its roofline.kernel_ms must agree)
 #   pmc_summary.json         three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM), tools/summarize_pmc.py
@@ -13,7 +14,10 @@ mkdir -p $out
 cd $root
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --workload ed > $out/bench_ed.json 2>> $out/bench.err
-python3 bench.py --workload fixed64 --steps 2 --warmup 1 > $out/bench_fixed64.json 2>> $out/bench.err
+python3 bench.py --workload fixed64 --steps 20 --warmup 2 > $out/bench_fixed64.json 2>> $out/bench.err
+MSM377_BENCH_PRECOMPUTE=20 python3 bench.py --workload fixed64 --steps 20 --warmup 2 > $out/bench_fixed64_wide.json 2>> $out/bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_driver_flags.json 2>> $out/bench.err
+python3 bench.py --steps 10 --warmup 2 --setup-msms 0 --no-cpu-baseline > $out/bench_r01_protocol.json 2>> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.log 2> $out/rocprof_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/rocprof_pmc1.err

@@ -50,8 +50,9 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   ctx->cap = max_points;
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_UPLOAD_SORT_ONCE")) ctx->upload_sort_once = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_TRACE")) ctx->upload_trace_on = atoi(e) != 0;
-  if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 8);
+  if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 7);
   if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 5), 90);
   if (const char* e = getenv("MSM377_UPLOAD_CHUNK_MIN")) ctx->upload_chunk_min = strtoull(e, nullptr, 10);
   if (const char* e = getenv("MSM377_TAIL_THREADS")) ctx->tail_threads = std::min(std::max(atoi(e), 1), TailPool::WORKERS + 1);
@@ -346,6 +347,7 @@ int msm377_ctx_get_stage_ms(msm377_ctx* ctx, double* ms_out) {
 }
 
 // ---- entry points that enqueue GPU work: sequencer.hip ----
+int msm377_ctx_reserve_host_staging(msm377_ctx* ctx) { return eng::reserve_host_staging(ctx); }
 int msm377_g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[96]) { return eng::g1_msm_device(ctx, d_points, d_scalars, n, out_xy); }
 int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) { return eng::g1_msm(ctx, points, scalars, n, out_xy); }
 int msm377_ed_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[64]) { return eng::ed_msm_device(ctx, d_points, d_scalars, n, out_xy); }

@@ -169,8 +169,9 @@ struct msm377_ctx {
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
   UploadTrace upload_trace;
   bool upload_trace_on = false;           // MSM377_UPLOAD_TRACE=1
-  uint32_t upload_chunks = 5;              // chunks of the points in the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..8)
-  uint32_t upload_split_pct = 16;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 5..90): it should land when the sort of the scalars is through
+  uint32_t upload_chunks = 4;              // chunks of the host-buffer upload (MSM377_UPLOAD_CHUNKS, 2..7): 2: 5.07, 3: 4.89, 4-6: 4.70, 8: 4.95 ms at 2^20 (round 2)
+  uint32_t upload_split_pct = 30;          // share of the points in the first chunk (MSM377_UPLOAD_SPLIT, 5..90)
+  bool upload_sort_once = false;           // MSM377_UPLOAD_SORT_ONCE=1: scalars first, one sort, chunks of points accumulate through their sub-rows (run_sorted_upload)
   std::function<int()> before_accumulate;  // host-buffer entry point: joins the point upload and launches the base conversion (enqueue_part)
   TailPool tail_pool;
   int tail_threads = 6;               // MSM377_TAIL_THREADS: threads of the host tail (1..8, tail_horner_mt)

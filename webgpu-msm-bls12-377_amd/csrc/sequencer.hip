@@ -70,6 +70,7 @@ void note_fallback(msm377_ctx* ctx, uint32_t mask) {
 // for a first hipMemcpy from fresh pageable pages (4.4 ms once the runtime has pinned them) and
 // 3.3 + 2.9 ms for hipHostRegister + copy.  Returns when the data is on the device.
 int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, size_t stage_off) {
+  using msm377::eng::reserve_host_staging;
   constexpr int NT_MAX = 8;
   constexpr int NT = 4;  // copy workers: 2, 4, 6 or 8 all moved 128 MB in 2.9-3.0 ms (round 2) -- the DMA sets the pace
   constexpr size_t SMALL = 8u << 20, PIECE = 4u << 20;
@@ -77,13 +78,10 @@ int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, s
     HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return MSM377_OK;
   }
-  if (!ctx->h_stage) {
-    if (hipHostMalloc((void**)&ctx->h_stage, (size_t)ctx->cap * 128) != hipSuccess) {
-      ctx->h_stage = nullptr;
-      HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));  // fall back to the runtime's pageable path
-      return MSM377_OK;
-    }
-    for (int t = 0; t < NT_MAX; t++) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
+  if (!ctx->h_stage && reserve_host_staging(ctx) != MSM377_OK) {
+    (void)hipGetLastError();
+    HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));  // fall back to the runtime's pageable path
+    return MSM377_OK;
   }
   // Pieces of about 4 MB, their number a multiple of the worker count: every worker copies the same amount (with
   // fixed 8 MB pieces a 48 MB upload took as long as a 64 MB one), and a worker's host copy of piece k+1 overlaps
@@ -745,18 +743,77 @@ int resident_table_to_weierstrass(msm377_ctx* ctx) {
   return MSM377_OK;
 }
 
-// Host-buffer entry points with large inputs: the upload (3.0 ms for the 128 MB of a 2^20-point G1 input from pageable
-// memory) is as long as the whole computation, so the two overlap -- and since round 3 the scalars go FIRST and are
-// decomposed and sorted ONCE, while the points (three quarters of the bytes) are still on their way in K chunks:
-//   1. all scalars up (32 n bytes), then decompose + sort of all 16 windows with the rows filed by chunk of the point
-//      index (k_local_sort_lds<true>: K sub-row bounds per key, common.hpp RowView)
-//   2. as each chunk of points lands: its base conversion, a work list over ITS sub-rows, the accumulation on top of the
-//      buckets the earlier chunks left (Phase::into), the merge of its split rows
-//   3. behind the last chunk: reduction, gather, D2H -- once.
-// Round 2 ran the whole front end per chunk (decompose and sort of the chunk's scalars four times over, ~0.15 ms each on
-// the GPU's critical path): 4.37 ms at 2^20 including the upload.  The accumulation of all chunks together (2.0 ms with
-// projective records) is about as long as the point upload (2.25 ms), so the call now ends one short chunk plus
-// reduction and tail behind the upload.  Returns with everything enqueued (slot 0).
+// Host-buffer entry points with large inputs: the upload (3.0-3.6 ms for the 128 MB of a 2^20-point G1 input from
+// pageable memory, box to box) is longer than the whole computation, so the two overlap: the MSM runs as K chunks of
+// points, later chunks accumulate on top of the buckets the earlier ones left (Phase::into), reduction, gather and D2H
+// are queued once, with the last chunk.  Two schedules:
+//
+// run_chunked_upload (DEFAULT): a chunk's scalars AND points go up together and the chunk runs the whole front end --
+// decompose .. accumulate .. merge -- while the next one is on its way.
+//
+// run_sorted_upload (MSM377_UPLOAD_SORT_ONCE=1): all scalars first, ONE decomposition and sort with
+// the rows filed by chunk of the point index (k_local_sort_lds<true>: K sub-row bounds per key, common.hpp RowView), then
+// per chunk of points only its base conversion, a work list over ITS sub-rows, the accumulation and the merge.  Built,
+// parity-green and NOT faster: same box, interleaved (profiles/r03_final/ab_upload.txt) 4.44 / 4.45 / 4.72 ms for the
+// per-chunk front ends against 4.67 / 4.67 / 4.74 sorted once.  The trace (MSM377_UPLOAD_TRACE=1,
+// profiles/r03_final/upload_trace.txt) says why: the call is bound by the GPU, not by the upload -- the chunks'
+// accumulations with projective records cost ~2.7 ms per 2^20 points (0.65 ms per 24 % chunk: short rows, a bucket
+// load and store per item and chunk, work list + merge per chunk) plus reduction and tail, and that work cannot start
+// before the first points are on the device; the per-chunk sorts the new schedule saves (~0.1 ms each) were hidden
+// behind the upload anyway, while its scalars-first head (0.78 ms of upload + 0.18 ms of sort before the first
+// accumulation) is not.
+template <class CV>
+int run_chunked_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n) {
+  constexpr size_t PB = CV::RAW_WORDS * 4;  // bytes per wire point
+  uint64_t cut[10];  // chunk c = points [cut[c], cut[c + 1]): the first one upload_split_pct of n, the rest even
+  uint32_t K = 0;
+  cut[0] = 0;
+  for (uint32_t c = 1; c < ctx->upload_chunks; c++) {
+    const uint64_t first_end = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull);
+    const uint64_t b = c == 1 ? first_end : (first_end + (n - first_end) * (c - 1) / (ctx->upload_chunks - 1)) & ~63ull;
+    if (b > cut[K] && b < n) cut[++K] = b;  // no empty chunks (small n)
+  }
+  cut[++K] = n;
+  const size_t sc_stage = (size_t)ctx->cap * 96;
+  auto upload_chunk = [&](uint32_t c) -> int {
+    const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+    int r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_scalars + first * 32, scalars + first * 32, cnt * 32, sc_stage + first * 32);
+    if (r == MSM377_OK) r = h2d_staged(ctx, (uint8_t*)ctx->d_raw_points + first * PB, points + first * PB, cnt * PB, first * PB);
+    return r;
+  };
+  int rc = upload_chunk(0);
+  if (rc) return rc;
+  int up_rc = MSM377_OK;
+  std::atomic<uint32_t> uploaded{1};  // chunks on the device so far
+  std::atomic<bool> upload_done{false};
+  std::thread upload([&] {
+    if (hipSetDevice(ctx->device) != hipSuccess) up_rc = MSM377_EHIP;
+    for (uint32_t c = 1; c < K && up_rc == MSM377_OK; c++) {
+      up_rc = upload_chunk(c);
+      if (up_rc == MSM377_OK) uploaded.store(c + 1, std::memory_order_release);
+    }
+    upload_done.store(true, std::memory_order_release);
+  });
+  for (uint32_t c = 0; c < K && rc == MSM377_OK; c++) {
+    while (uploaded.load(std::memory_order_acquire) <= c && !upload_done.load(std::memory_order_acquire)) std::this_thread::yield();
+    if (uploaded.load(std::memory_order_acquire) <= c) {  // the upload thread stopped on an error
+      rc = up_rc ? up_rc : MSM377_EHIP;
+      break;
+    }
+    const uint64_t first = cut[c], cnt = cut[c + 1] - cut[c];
+    Phase ph;
+    ph.clear_err = c == 0;
+    ph.into = c > 0;
+    ph.back = c + 1 == K;
+    ph.base_first = first;
+    rc = convert_bases<CV>(ctx, ctx->d_raw_points + first * CV::RAW_WORDS, cnt, first, c == 0);
+    if (rc == MSM377_OK) rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+  }
+  upload.join();
+  if (rc) (void)hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+
 template <class CV>
 int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n) {
   constexpr size_t PB = CV::RAW_WORDS * 4;  // bytes per wire point
@@ -764,8 +821,8 @@ int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sca
   // the last one half a share (only ITS accumulation trails the upload), the rest even; multiples of 64 points
   ChunkCuts cuts;
   {
-    const uint32_t want = std::min<uint32_t>(ctx->upload_chunks, MAX_UPLOAD_CHUNKS);
-    const uint64_t first_end = std::max<uint64_t>(64, (n * ctx->upload_split_pct / 100) & ~63ull);
+    const uint32_t want = std::min<uint32_t>(ctx->upload_chunks + 1, MAX_UPLOAD_CHUNKS);  // one chunk more than the default schedule: its last one is half a share
+    const uint64_t first_end = std::max<uint64_t>(64, (n * (ctx->upload_split_pct * 5 / 9) / 100) & ~63ull);  // 30 % -> 16 %: the first chunk should land when the sort is through
     const double rest = (double)(n - std::min(n, first_end)), shares = want > 2 ? (double)(want - 2) + 0.5 : 1.0;
     uint32_t K = 0;
     cuts.cut[0] = 0;
@@ -866,6 +923,23 @@ int check_args(msm377_ctx* ctx, const void* a, const void* b, uint64_t n, bool n
 
 // ---- entry points (C ABI: capi.hip forwards) ----
 
+// The pinned staging buffer (128 bytes per point of capacity) and the copy streams of the host-buffer entry points.
+// h2d_staged allocates them on first use -- which made the FIRST host-buffer call of a context ~35 ms; a caller that
+// cares calls this right after msm377_ctx_create.
+int reserve_host_staging(msm377_ctx* ctx) {
+  if (!ctx) return MSM377_EINVAL;
+  if (ctx->h_stage) return MSM377_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (hipHostMalloc((void**)&ctx->h_stage, (size_t)ctx->cap * 128) != hipSuccess) {
+    ctx->h_stage = nullptr;
+    ctx->err = "host staging buffer: out of pinned memory";
+    return MSM377_ENOMEM;
+  }
+  for (int t = 0; t < 8; t++)
+    if (!ctx->copy_stream[t]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[t], hipStreamNonBlocking));
+  return MSM377_OK;
+}
+
 int g1_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint8_t out_xy[96]) {
   if (!out_xy) return MSM377_EINVAL;
   int rc = check_args(ctx, d_points, d_scalars, n, true);
@@ -918,7 +992,10 @@ int g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
   int rc;
   if (n >= ctx->upload_chunk_min && form != TABLE_XYZZ_GLV && !ctx->capture) {  // (stage read-backs describe the plain row layout)
     const bool te = form == TABLE_TE;
-    rc = te ? run_sorted_upload<TeDev>(ctx, points, scalars, n) : run_sorted_upload<G1Dev>(ctx, points, scalars, n);
+    if (ctx->upload_sort_once)
+      rc = te ? run_sorted_upload<TeDev>(ctx, points, scalars, n) : run_sorted_upload<G1Dev>(ctx, points, scalars, n);
+    else
+      rc = te ? run_chunked_upload<TeDev>(ctx, points, scalars, n) : run_chunked_upload<G1Dev>(ctx, points, scalars, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     ctx->upload_trace.report();
@@ -1000,7 +1077,7 @@ int ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n >= ctx->upload_chunk_min) {  // chunks of points, like g1_msm: a chunk computes while the next one uploads
     ctx->bases_n = 0;
-    int rc = run_sorted_upload<EdDev>(ctx, points, scalars, n);
+    int rc = ctx->upload_sort_once ? run_sorted_upload<EdDev>(ctx, points, scalars, n) : run_chunked_upload<EdDev>(ctx, points, scalars, n);
     if (rc) return rc;
     rc = finish_windows(ctx, 0);
     if (rc) return rc;

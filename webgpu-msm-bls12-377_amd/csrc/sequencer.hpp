@@ -25,6 +25,8 @@ int window_partials(msm377_ctx* ctx, const void* d_points, const void* d_scalars
 int g1_glv_window_partials_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, uint64_t n, uint32_t win_begin, uint32_t win_count, uint8_t* partials_out);
 int g1_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d_points_out);
 
+int reserve_host_staging(msm377_ctx* ctx);
+
 // Shared with capi.hip (argument checks of the host-only entry points, the stage read-back).
 bool hip_ok(msm377_ctx* ctx, int hip_error, const char* what);
 

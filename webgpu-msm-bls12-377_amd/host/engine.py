@@ -110,6 +110,7 @@ def load_library():
         "msm377_ctx_get_products_per_addition": (i32, [vp]),
         "msm377_ctx_set_precompute_window": (i32, [vp, i32]),
         "msm377_g1_add_points": (i32, [vp, u32, vp]),
+        "msm377_ctx_reserve_host_staging": (i32, [vp]),
         "msm377_ctx_get_stage_form": (i32, [vp]),
         "msm377_ctx_set_narrow_max": (i32, [vp, u64]),
     }
@@ -261,6 +262,11 @@ class MsmEngine:
         if len(points) % 96:
             raise ValueError("points buffer length must be a multiple of 96")
         self._check(self._lib.msm377_g1_set_bases_precomputed(self._ctx, bytes(points), len(points) // 96), "msm377_g1_set_bases_precomputed")
+
+    def reserve_host_staging(self):
+        """Allocate the pinned staging of the host-buffer entry points now instead of inside the first call
+        (msm377_ctx_reserve_host_staging)."""
+        self._check(self._lib.msm377_ctx_reserve_host_staging(self._ctx), "msm377_ctx_reserve_host_staging")
 
     def set_precompute_window(self, window_bits: int):
         """Window width of the next precomputed table: 16 (16 windows) or 20 (13 windows over one set of 2^19 buckets,
