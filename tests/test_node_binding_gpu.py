@@ -36,3 +36,20 @@ def test_compute_msm_js(golden, name):
     assert got["empty_x"] == "0" and got["empty_y"] == "1"  # submission.ts:93-95
     assert got["version"].startswith("msm377")
     assert got["forms"] == 3  # Buffer, BigIntPoint[] / bigint[] and U32ArrayPoint[] / Uint32Array[] all went through the addon and agreed
+
+
+@pytest.mark.parametrize("name", ["ed_n24_random", "ed_n10_edge_scalars", "ed_n2_cancel"])
+def test_compute_msm_edwards_js(golden, name):
+    """The Edwards-BLS12 twin through the addon (computeEdMsmSync -> msm377_ed_msm) on the Edwards golden cases."""
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this box")
+    case = golden[name]
+    proc = subprocess.run(
+        [node, os.path.join(NODE_DIR, "run_golden.js"), os.path.join(util.GOLDEN_DIR, name + ".bin"), str(case["n"]), "ed"],
+        capture_output=True, text=True, timeout=300,
+    )
+    assert proc.returncode == 0, proc.stderr
+    got = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert got["x"] == str(int.from_bytes(case["expected"][:32], "little")) and got["y"] == str(int.from_bytes(case["expected"][32:], "little"))
+    assert got["empty_x"] == "0" and got["empty_y"] == "1"

@@ -51,6 +51,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_SORT_ONCE")) ctx->upload_sort_once = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_AFF_PREWAKE_US")) ctx->aff_prewake_us = atoll(e);
   if (const char* e = getenv("MSM377_UPLOAD_TRACE")) ctx->upload_trace_on = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 7);
   if (const char* e = getenv("MSM377_UPLOAD_SPLIT")) ctx->upload_split_pct = (uint32_t)std::min(std::max(atoi(e), 5), 90);
@@ -80,6 +81,8 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   int prio_least = 0, prio_greatest = 0;
   bool ok = hipSetDevice(device) == hipSuccess;
   if (ok && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
+  // (Round 3 re-measured the priorities with the faster sort, now that the conversion chain is the front end's critical
+  // path: main stream high 2.554 ms, side stream high 2.583, equal 2.603 at 2^20 -- profiles/r03_final/ab_prio_prewake.txt.)
   ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess &&

@@ -179,6 +179,10 @@ struct msm377_ctx {
   // 0 = they sleep until the job is posted).  Tail stage at 2^20, interleaved (tools/ab_knobs.py): one thread 0.140 ms,
   // six sleeping workers 0.124, six polling ones 0.089.  (Round 2 first measured no difference: the per-thread
   // exceptional-case flags shared a cache line then and the threads fought over it -- TeChecked is padded now.)
+  // MSM377_AFF_PREWAKE_US: the helper threads that invert the conversion's block products are woken when the way up is
+  // queued and poll for their share (at most this long) instead of being woken from their condition variable when the
+  // products arrive -- the wake-up (20-60 us) sat in the middle of the front end's critical path.  0 = off.
+  int64_t aff_prewake_us = 600;
   int64_t tail_spin_us = 1000;
   bool tail_trace = false;  // MSM377_TAIL_TRACE=1
   double stage_ms[MSM377_NUM_STAGES] = {};

@@ -170,6 +170,7 @@ int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, con
                        ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->aff_up_done, ctx->stream2));
+  if (ctx->tail_threads > 1 && nblk >= 32) ctx->tail_pool.prewake(ctx->aff_prewake_us, std::min(ctx->tail_threads, TailPool::WORKERS + 1) - 1);
   return MSM377_OK;
 }
 
@@ -194,6 +195,7 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
   }
   {
     const int inv_rc = invert_block_products_mt(ctx, 0, nblk);
+    ctx->tail_pool.disarm();  // (armed by affine_convert_begin; the tail arms them again once the accumulation is through)
     if (inv_rc) return inv_rc;
   }
   // The way down starts as soon as the host has inverted the block products, beside whatever the sort is doing (letting

@@ -56,4 +56,23 @@ const compute_msm = async (baseAffinePoints, scalars, log_result = true, force_r
   return r;
 };
 
-module.exports = { compute_msm, pointsToBuffer, scalarsToBuffer, version: addon.version };
+// The Edwards-BLS12 twin (BASELINE.json config 3; the reference's orphaned Edwards shaders,
+// /root/reference/src/submission/miscellaneous/wgsl/add_points_any_a.template.wgsl:24-71): 64-byte points x || y,
+// 32-byte little-endian each (README.md:299-301); returns {x, y}, the neutral element as (0, 1).
+const compute_msm_edwards = (points, scalars) => {
+  if (scalars.length === 0) return { x: BigInt(0), y: BigInt(1) };
+  const out = addon.computeEdMsmSync(points, scalars);
+  return { x: leBufferToBigInt(out.slice(0, 32)), y: leBufferToBigInt(out.slice(32, 64)) };
+};
+
+// Fixed-base batches (BASELINE.json config 5): convert and keep a base set in HBM once, then any number of MSMs of
+// n <= its size against it (msm377_g1_set_bases / msm377_g1_msm_fixed_base).
+const set_bases = (baseAffinePoints) => addon.setBasesSync(pointsToBuffer(baseAffinePoints));
+const compute_msm_fixed_base = (scalars) => {
+  const scalarsBuf = scalarsToBuffer(scalars);
+  if (scalarsBuf.length === 0) return { x: BigInt(0), y: BigInt(1) };
+  const out = addon.fixedBaseMsmSync(scalarsBuf);
+  return { x: leBufferToBigInt(out.slice(0, 48)), y: leBufferToBigInt(out.slice(48, 96)) };
+};
+
+module.exports = { compute_msm, compute_msm_edwards, set_bases, compute_msm_fixed_base, pointsToBuffer, scalarsToBuffer, version: addon.version };

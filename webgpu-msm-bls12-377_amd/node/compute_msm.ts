@@ -14,6 +14,9 @@ import { BigIntPoint, U32ArrayPoint } from "../reference/types";
 const addon: {
   computeMsm(points: Buffer, scalars: Buffer): Promise<Buffer>;
   computeMsmSync(points: Buffer, scalars: Buffer): Buffer;
+  computeEdMsmSync(points: Buffer, scalars: Buffer): Buffer;
+  setBasesSync(points: Buffer): void;
+  fixedBaseMsmSync(scalars: Buffer): Buffer;
   version(): string;
 } = require("./msm377/build/msm377_napi.node");
 
@@ -78,4 +81,30 @@ export const compute_msm = async (
     console.log(r);
   }
   return r;
+};
+
+// The Edwards-BLS12 twin (BASELINE.json config 3; the reference's orphaned Edwards shaders,
+// src/submission/miscellaneous/wgsl/add_points_any_a.template.wgsl:24-71): 64-byte points x || y, 32-byte
+// little-endian each (README.md:299-301); the neutral element is (0, 1).
+export const compute_msm_edwards = (points: Buffer, scalars: Buffer): { x: bigint; y: bigint } => {
+  if (scalars.length === 0) {
+    return { x: BigInt(0), y: BigInt(1) };
+  }
+  const out: Buffer = addon.computeEdMsmSync(points, scalars);
+  return { x: leBufferToBigInt(out.subarray(0, 32) as Buffer), y: leBufferToBigInt(out.subarray(32, 64) as Buffer) };
+};
+
+// Fixed-base batches (BASELINE.json config 5): convert and keep a base set in HBM once, then any number of MSMs of
+// n <= its size against it (msm377_g1_set_bases / msm377_g1_msm_fixed_base).
+export const set_bases = (baseAffinePoints: BigIntPoint[] | U32ArrayPoint[] | Buffer): void => {
+  addon.setBasesSync(pointsToBuffer(baseAffinePoints));
+};
+
+export const compute_msm_fixed_base = (scalars: bigint[] | Uint32Array[] | Buffer): { x: bigint; y: bigint } => {
+  const scalarsBuf = scalarsToBuffer(scalars);
+  if (scalarsBuf.length === 0) {
+    return { x: BigInt(0), y: BigInt(1) };
+  }
+  const out: Buffer = addon.fixedBaseMsmSync(scalarsBuf);
+  return { x: leBufferToBigInt(out.subarray(0, 48) as Buffer), y: leBufferToBigInt(out.subarray(48, 96) as Buffer) };
 };

@@ -8,6 +8,9 @@
 // in JS):
 //   computeMsm(points: Buffer, scalars: Buffer): Promise<Buffer>   96-byte x||y, runs off the JS thread
 //   computeMsmSync(points: Buffer, scalars: Buffer): Buffer
+//   computeEdMsmSync(points: Buffer 64n, scalars: Buffer 32n): Buffer   the Edwards-BLS12 twin (msm377_ed_msm), 64-byte x||y
+//   setBasesSync(points: Buffer 96n): void                             fixed-base batches: keep a converted base set in HBM ...
+//   fixedBaseMsmSync(scalars: Buffer 32n): Buffer                      ... and run MSMs of n <= its size against it
 //   version(): string
 // Errors reject / throw a JS Error carrying msm377_strerror + msm377_last_error, matching the
 // reference's behaviour of throwing Error (cuzk/gpu.ts:7-10).
@@ -57,7 +60,7 @@ int run(const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out[9
   return rc;
 }
 
-bool get_buffers(napi_env env, napi_callback_info info, uint8_t** p, size_t* pl, uint8_t** s, size_t* sl) {
+bool get_buffers(napi_env env, napi_callback_info info, uint8_t** p, size_t* pl, uint8_t** s, size_t* sl, size_t point_bytes = 96) {
   size_t argc = 2;
   napi_value argv[2];
   if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < 2) {
@@ -73,8 +76,8 @@ bool get_buffers(napi_env env, napi_callback_info info, uint8_t** p, size_t* pl,
   }
   napi_get_buffer_info(env, argv[0], reinterpret_cast<void**>(p), pl);
   napi_get_buffer_info(env, argv[1], reinterpret_cast<void**>(s), sl);
-  if (*sl % 32 != 0 || *pl != (*sl / 32) * 96) {
-    napi_throw_range_error(env, nullptr, "points must hold 96 bytes and scalars 32 bytes per input");
+  if (*sl % 32 != 0 || *pl != (*sl / 32) * point_bytes) {
+    napi_throw_range_error(env, nullptr, point_bytes == 96 ? "points must hold 96 bytes and scalars 32 bytes per input" : "points must hold 64 bytes and scalars 32 bytes per input");
     return false;
   }
   return true;
@@ -87,6 +90,89 @@ napi_value ComputeMsmSync(napi_env env, napi_callback_info info) {
   uint8_t out[96];
   std::string err;
   if (run(p, s, sl / 32, out, &err)) {
+    napi_throw_error(env, nullptr, err.c_str());
+    return nullptr;
+  }
+  napi_value buf;
+  void* data;
+  napi_create_buffer_copy(env, 96, out, &data, &buf);
+  return buf;
+}
+
+// ---- the other entry points of the C ABI a TypeScript host may want (synchronous forms) ----
+napi_value ComputeEdMsmSync(napi_env env, napi_callback_info info) {
+  uint8_t *p, *s;
+  size_t pl, sl;
+  if (!get_buffers(env, info, &p, &pl, &s, &sl, 64)) return nullptr;
+  uint8_t out[64];
+  std::string err;
+  int rc;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    rc = ensure_ctx(sl / 32 ? sl / 32 : 1, &err);
+    if (!rc) {
+      rc = msm377_ed_msm(g_ctx, p, s, sl / 32, out);
+      if (rc) err = std::string("msm377_ed_msm: ") + msm377_strerror(rc) + ": " + msm377_last_error(g_ctx);
+    }
+  }
+  if (rc) {
+    napi_throw_error(env, nullptr, err.c_str());
+    return nullptr;
+  }
+  napi_value buf;
+  void* data;
+  napi_create_buffer_copy(env, 64, out, &data, &buf);
+  return buf;
+}
+
+bool one_buffer(napi_env env, napi_callback_info info, uint8_t** p, size_t* len, size_t unit, const char* what) {
+  size_t argc = 1;
+  napi_value argv[1];
+  bool is_buf = false;
+  if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < 1 || napi_is_buffer(env, argv[0], &is_buf) != napi_ok || !is_buf) {
+    napi_throw_type_error(env, nullptr, what);
+    return false;
+  }
+  napi_get_buffer_info(env, argv[0], reinterpret_cast<void**>(p), len);
+  if (*len % unit) {
+    napi_throw_range_error(env, nullptr, what);
+    return false;
+  }
+  return true;
+}
+
+napi_value SetBasesSync(napi_env env, napi_callback_info info) {
+  uint8_t* p;
+  size_t len;
+  if (!one_buffer(env, info, &p, &len, 96, "expected (points: Buffer of 96 bytes per point)")) return nullptr;
+  std::string err;
+  std::lock_guard<std::mutex> lock(g_mu);
+  int rc = ensure_ctx(len / 96 ? len / 96 : 1, &err);
+  if (!rc) {
+    rc = msm377_g1_set_bases(g_ctx, p, len / 96);
+    if (rc) err = std::string("msm377_g1_set_bases: ") + msm377_strerror(rc) + ": " + msm377_last_error(g_ctx);
+  }
+  if (rc) napi_throw_error(env, nullptr, err.c_str());
+  return nullptr;
+}
+
+napi_value FixedBaseMsmSync(napi_env env, napi_callback_info info) {
+  uint8_t* s;
+  size_t len;
+  if (!one_buffer(env, info, &s, &len, 32, "expected (scalars: Buffer of 32 bytes per scalar)")) return nullptr;
+  uint8_t out[96];
+  std::string err;
+  int rc = MSM377_ESTATE;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_ctx || g_cap < len / 32) {
+      err = "fixedBaseMsmSync: call setBasesSync with at least as many points first";
+    } else {
+      rc = msm377_g1_msm_fixed_base(g_ctx, s, len / 32, out);
+      if (rc) err = std::string("msm377_g1_msm_fixed_base: ") + msm377_strerror(rc) + ": " + msm377_last_error(g_ctx);
+    }
+  }
+  if (rc) {
     napi_throw_error(env, nullptr, err.c_str());
     return nullptr;
   }
@@ -162,6 +248,9 @@ napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"computeMsm", nullptr, ComputeMsm, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"computeMsmSync", nullptr, ComputeMsmSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"computeEdMsmSync", nullptr, ComputeEdMsmSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setBasesSync", nullptr, SetBasesSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"fixedBaseMsmSync", nullptr, FixedBaseMsmSync, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"version", nullptr, Version, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);

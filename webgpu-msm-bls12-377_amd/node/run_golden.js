@@ -2,7 +2,17 @@
 // Test driver: node run_golden.js <case.bin> <n>  -> prints {"x": "...", "y": "..."} (decimal),
 // the way the harness compares results (toString equality, src/ui/Benchmark.tsx:41-48).
 const fs = require('fs');
-const { compute_msm, version } = require('./compute_msm.js');
+const { compute_msm, compute_msm_edwards, set_bases, compute_msm_fixed_base, version } = require('./compute_msm.js');
+
+// node run_golden.js <ed case.bin> <n> ed  -> the Edwards-BLS12 twin on an Edwards golden case (64-byte points)
+if (process.argv[4] === 'ed') {
+  const blob = fs.readFileSync(process.argv[2]);
+  const n = parseInt(process.argv[3], 10);
+  const r = compute_msm_edwards(blob.slice(0, 64 * n), blob.slice(64 * n, 96 * n));
+  const empty = compute_msm_edwards(Buffer.alloc(0), Buffer.alloc(0));
+  console.log(JSON.stringify({ x: r.x.toString(), y: r.y.toString(), empty_x: empty.x.toString(), empty_y: empty.y.toString() }));
+  process.exit(0);
+}
 
 (async () => {
   const blob = fs.readFileSync(process.argv[2]);
@@ -33,6 +43,17 @@ const { compute_msm, version } = require('./compute_msm.js');
   const ks32 = ks.map((k) => u32(k, 256));
   const r3 = await compute_msm(pts32, ks32, false);
   if (r3.x !== r.x || r3.y !== r.y) throw new Error('U32ArrayPoint[] form disagrees with Buffer form');
+  // fixed-base form: the same points resident, the same scalars -> the same result; a prefix of the scalars against the
+  // resident set agrees with the plain call on that prefix
+  set_bases(points);
+  const r4 = compute_msm_fixed_base(scalars);
+  if (r4.x !== r.x || r4.y !== r.y) throw new Error('fixed-base form disagrees with the plain call');
+  if (n > 1) {
+    const half = n >> 1;
+    const a = compute_msm_fixed_base(scalars.slice(0, 32 * half));
+    const b = await compute_msm(points.slice(0, 96 * half), scalars.slice(0, 32 * half), false);
+    if (a.x !== b.x || a.y !== b.y) throw new Error('fixed-base prefix disagrees with the plain call');
+  }
   const empty = await compute_msm(Buffer.alloc(0), Buffer.alloc(0), false);
   console.log(JSON.stringify({ forms: 3, x: r.x.toString(), y: r.y.toString(), empty_x: empty.x.toString(), empty_y: empty.y.toString(), version: version() }));
 })().catch((e) => {
