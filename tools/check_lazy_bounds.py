@@ -196,6 +196,45 @@ def te_formulas(canonical):
     mul_lz(PX, canonical, "gather X*TO64")
 
 
+def csub_mod(a, name):
+    """field29.hpp csub(x, MOD): x N-form; subtracts p once if x >= p."""
+    assert a.normalised, name
+    return nform(max(P, a.hi - P), 0, name)
+
+
+def conversion_formulas():
+    """kernels/convert.hpp, the batched affine conversion in lazy forms (AffWireSource::load, k_affine_up, k_affine_down)."""
+    canonical = nform(P, 0, "canonical")
+    zero = V([0] * N, 1, 0, "zero")
+    u = add_lz(mul_lz(canonical, canonical, "conv x*SR"), canonical, "conv u")
+    v = mul_lz(canonical, canonical, "conv v")
+    cu = csub_mod(norm(add_lz(mul_lz(canonical, canonical, "conv x*CSR"), canonical, "conv cu"), "conv cu"), "conv cu")
+    assert cu.hi <= P + E, cu.hi / P
+    up = add_lz(u, canonical, "conv u+1")
+    assert max(up.limbs[:-1]) < 3 * BETA and up.limbs[-1] < (1 << 31)
+    z = mul_lz(up, v, "conv z")
+    n1 = mul_lz(up, cu, "conv n1")
+    n2 = norm(add_kp_sub(z, "KP4W3", 4, zero, "conv n2", b2=v), "conv n2")
+    assert n2.lo > 0 and n2.hi <= 5 * P + E, (n2.lo, n2.hi / P)
+    c = mul_lz(m1("c"), z, "conv c*z")
+    node = mul_lz(c, c, "conv tree node")
+    root = mul_lz(node, canonical, "conv root*TO64")  # then reduce_once: needs < 2p
+    assert root.hi <= 2 * P
+    inv = mul_lz(canonical, node, "conv tree down")  # the host's inverse is canonical; further down N x N
+    inv = mul_lz(inv, node, "conv tree down 2")
+    zi = mul_lz(inv, c, "conv zi")
+    inv = mul_lz(inv, z, "conv inv*Z")
+    x = mul_lz(n1, zi, "conv x")  # then reduce_once -> canonical
+    y = mul_lz(n2, zi, "conv y")
+    assert x.hi <= 2 * P and y.hi <= 2 * P
+    kt = mul_lz(mul_lz(canonical, canonical, "conv xy"), canonical, "conv 2dxy")
+    # the record's kt is now a lazy product, its y -+ x stay canonical: replay the affine mixed addition with it
+    PX, PY, PT, PZ = m1("PX"), m1("PY"), m1("PT"), m1("PZ")
+    mul_lz(kp_sub("KP2", 2, kt, "conv-rec -kt"), PT, "conv-rec C neg")
+    mul_lz(kt, PT, "conv-rec C")
+    mul_lz(kt, canonical, "conv-rec first: kt / d")  # from_base_affine: mul(kt, TE_INV_D), reduce_once needs < 2p
+
+
 def main():
     use_field("Fq")  # Edwards-BLS12 buckets (EdDev): same law over the 9-limb field
     te_formulas(nform(P, 0, "canonical"))
@@ -230,6 +269,7 @@ def main():
     canon_ok(y, "quad canon(Y3)")
 
     te_formulas(canonical)
+    conversion_formulas()
 
     # canonical operations on stored (lazy) coordinates: mul() = reduce_once(mul_lz()) needs mul_lz < 2p
     mul_lz(X1, canonical, "gather X*TO64")

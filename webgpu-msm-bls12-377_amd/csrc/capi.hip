@@ -51,6 +51,8 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_GLV")) ctx->glv_mode = atoi(e);
   if (const char* e = getenv("MSM377_G1_FORM")) ctx->g1_form = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_SORT_ONCE")) ctx->upload_sort_once = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_CONV_WAVE_PRIO")) ctx->conv_wave_prio = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_FRONT_WAVE_PRIO")) ctx->front_wave_prio = atoi(e) != 0;
   if (const char* e = getenv("MSM377_AFF_PREWAKE_US")) ctx->aff_prewake_us = atoll(e);
   if (const char* e = getenv("MSM377_UPLOAD_TRACE")) ctx->upload_trace_on = atoi(e) != 0;
   if (const char* e = getenv("MSM377_UPLOAD_CHUNKS")) ctx->upload_chunks = (uint32_t)std::min(std::max(atoi(e), 2), 7);

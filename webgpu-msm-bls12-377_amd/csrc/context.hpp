@@ -183,6 +183,10 @@ struct msm377_ctx {
   // queued and poll for their share (at most this long) instead of being woken from their condition variable when the
   // products arrive -- the wake-up (20-60 us) sat in the middle of the front end's critical path.  0 = off.
   int64_t aff_prewake_us = 600;
+  // MSM377_FRONT_WAVE_PRIO: the memory-bound front-end kernels (decompose, sort, work list) raise their waves' issue priority
+  // (s_setprio 3) over the VALU-bound base conversion that runs beside them on the side stream.
+  uint32_t front_wave_prio = 0;
+  uint32_t conv_wave_prio = 1;  // MSM377_CONV_WAVE_PRIO: the same for the conversion kernels (k_affine_up / k_affine_down)
   int64_t tail_spin_us = 1000;
   bool tail_trace = false;  // MSM377_TAIL_TRACE=1
   double stage_ms[MSM377_NUM_STAGES] = {};

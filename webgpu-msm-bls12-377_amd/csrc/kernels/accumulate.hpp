@@ -55,7 +55,8 @@ __device__ __forceinline__ RowSplit row_split(uint32_t len, uint32_t SEG) {
 // atomic per bin and block -- the ~60 hot counters serialise, hence the large blocks); rows with more than one item reserve overflow slots and join the split-row list.
 __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ work_hist,
                                                    uint32_t* __restrict__ row_ovf_base, uint32_t* __restrict__ counters /* [0]=split rows, [1]=overflow slots */,
-                                                   uint32_t* __restrict__ split_rows, RowView rv) {
+                                                   uint32_t* __restrict__ split_rows, RowView rv, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t blk[4];  // split rows, overflow slots of this block; then their bases in the global lists
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
@@ -89,7 +90,8 @@ __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__
 }
 
 // One block (SEG_BINS <= 256): cursor[b] = number of items longer than b (descending order), total item count.
-__global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ work_hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ total) {
+__global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ work_hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ total, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t h[SEG_BINS];
   const uint32_t tid = threadIdx.x;
   if (tid < SEG_BINS) h[tid] = work_hist[tid];
@@ -104,7 +106,8 @@ __global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ 
 
 // Thread per row again: claims its slots in the sorted work list.
 __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ cursor,
-                                                      WorkItem* __restrict__ work, RowView rv) {
+                                                      WorkItem* __restrict__ work, RowView rv, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t lbase[SEG_BINS];
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;

@@ -68,15 +68,19 @@ struct AffWireSource {  // wire format (x || y, canonical Weierstrass coordinate
     using K = G1Consts;
     uint32_t w[24];
     load_words16(raw + i * 24, w, 6);
-    const Fp::El xr = Fp::from_words<12>(w), yr = Fp::from_words<12>(w + 12);
-    const Fp::El u = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_SR)), Fp::from_const(K::TE_S));
-    const Fp::El v = Fp::mul(yr, Fp::from_const(K::TE_SR));
-    const Fp::El cu = Fp::add(Fp::mul(xr, Fp::from_const(K::TE_CSR)), Fp::from_const(K::TE_CS));
-    const Fp::El up = Fp::add(u, Fp::one());
-    z = Fp::mul(v, up);
-    n1 = Fp::mul(cu, up);
-    n2 = Fp::sub(z, Fp::dbl(v));  // (u - 1) v = (u + 1) v - 2 v
-    return Fp::is_zero(z);
+    // The lazy field forms of field29.hpp (round 3; bounds replayed by tools/check_lazy_bounds.py conversion_formulas):
+    // products without the conditional subtraction, sums limb-wise.  ~630 of the ~3 700 instructions per point less, and
+    // none of the 13-step borrow chains of the canonical add / sub, which is what two waves per SIMD could not hide.
+    const Fp::El xr = Fp::from_words<12>(w), yr = Fp::from_words<12>(w + 12);                      // canonical
+    const Fp::El u = Fp::add_lz(Fp::mul_lz(xr, Fp::from_const(K::TE_SR)), Fp::from_const(K::TE_S));  // limbs < 2^30
+    const Fp::El v = Fp::mul_lz(yr, Fp::from_const(K::TE_SR));                                      // < p + 2^354
+    // c u is the one factor that has to come back below p + 2^354 (n1 multiplies it by the limb-wise u + 1)
+    const Fp::El cu = Fp::csub(Fp::norm(Fp::add_lz(Fp::mul_lz(xr, Fp::from_const(K::TE_CSR)), Fp::from_const(K::TE_CS))), K::MOD);
+    const Fp::El up = Fp::add_lz(u, Fp::one());                                                     // limbs < 3 * 2^29
+    z = Fp::mul_lz(up, v);
+    n1 = Fp::mul_lz(up, cu);
+    n2 = Fp::norm(Fp::add_kp_sub_sub2(z, K::KP4W3, Fp::zero(), v));  // (u - 1) v = (u + 1) v - 2 v (+ 4p): N-form below 5p + 2^354
+    return Te377::is_zero_mod_p(z);
   }
 };
 struct AffDoublingSource {  // [2^bits] of the point in an affine record of the previous window's table (precomputed-window tables)
@@ -104,7 +108,8 @@ struct AffDoublingSource {  // [2^bits] of the point in an affine record of the 
 template <class SRC>
 __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t n, uint32_t* __restrict__ stash,
                                                               uint32_t* __restrict__ trees, uint32_t* __restrict__ block_prod, uint32_t* __restrict__ host_flag, uint32_t* __restrict__ dev_count,
-                                                              int* __restrict__ err) {
+                                                              int* __restrict__ err, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: the conversion is the front end's critical path
   // block_prod and host_flag live in pinned, coherent HOST memory: the host polls the flag and starts inverting the
   // moment the last workgroup has delivered (a D2H copy queued behind this kernel took 60 us to get through beside the
   // sort, and an event wait adds its wake-up latency on top).  Workgroups count themselves in DEVICE memory -- a
@@ -133,13 +138,13 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
     uint4* dst = reinterpret_cast<uint4*>(stash) + ((size_t)blk * AFF_K + j) * (AFF_STASH_WORDS / 4) * AFF_THREADS + tid;
 #pragma unroll
     for (int k = 0; k < (int)AFF_STASH_WORDS / 4; k++) dst[(size_t)k * AFF_THREADS] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    c = Fp::mul(c, z);
+    c = Fp::mul_lz(c, z);
   }
   if (bad) atomicOr(err, ERR_TE_CONVERT);
   put13(tree[AFF_THREADS + tid], c);
   for (uint32_t size = AFF_THREADS / 2; size >= 1; size >>= 1) {
     __syncthreads();
-    if (tid < size) put13(tree[size + tid], Fp::mul(get13(tree[2 * (size + tid)]), get13(tree[2 * (size + tid) + 1])));
+    if (tid < size) put13(tree[size + tid], Fp::mul_lz(get13(tree[2 * (size + tid)]), get13(tree[2 * (size + tid) + 1])));
   }
   __syncthreads();
   uint32_t* out = trees + (size_t)blk * (2 * AFF_THREADS * 13);
@@ -163,7 +168,8 @@ __global__ void __launch_bounds__(AFF_THREADS, 4) k_affine_up(SRC src, uint64_t 
 // block_inv: 12 words per workgroup, the inverse of its product as a DEVICE Montgomery residue (the host re-bases);
 // read straight from pinned host memory.
 __global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, const uint32_t* __restrict__ stash, const uint32_t* __restrict__ trees,
-                                                                const uint32_t* __restrict__ block_inv, uint32_t* __restrict__ bases) {
+                                                                const uint32_t* __restrict__ block_inv, uint32_t* __restrict__ bases, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: the conversion is the front end's critical path
   __shared__ uint32_t tree[2 * AFF_THREADS][13];
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
   const uint32_t* in = trees + (size_t)blk * (2 * AFF_THREADS * 13);
@@ -182,8 +188,8 @@ __global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, cons
     if (tid < size) {
       const uint32_t k = size + tid;
       const Fp::El inv_k = get13(tree[k]), a = get13(tree[2 * k]), b = get13(tree[2 * k + 1]);
-      put13(tree[2 * k], Fp::mul(inv_k, b));
-      put13(tree[2 * k + 1], Fp::mul(inv_k, a));
+      put13(tree[2 * k], Fp::mul_lz(inv_k, b));
+      put13(tree[2 * k + 1], Fp::mul_lz(inv_k, a));
     }
   }
   __syncthreads();
@@ -205,10 +211,11 @@ __global__ void __launch_bounds__(AFF_THREADS, 2) k_affine_down(uint64_t n, cons
         w[4 * k + 3] = v.w;
       }
     }
-    const Fp::El zi = Fp::mul(inv, get13(w + 39));  // 1 / Z_j = (1 / C_j) C_(j-1)
-    inv = Fp::mul(inv, get13(w + 26));              // 1 / C_(j-1)
-    const Fp::El x = Fp::mul(get13(w), zi), y = Fp::mul(get13(w + 13), zi);
-    const Fp::El ymx = Fp::sub(y, x), ypx = Fp::add(y, x), kt = Fp::mul(Fp::mul(x, y), Fp::from_const(G1Consts::TE_2D));
+    const Fp::El zi = Fp::mul_lz(inv, get13(w + 39));  // 1 / Z_j = (1 / C_j) C_(j-1)
+    inv = Fp::mul_lz(inv, get13(w + 26));              // 1 / C_(j-1)
+    const Fp::El x = Fp::mul(get13(w), zi), y = Fp::mul(get13(w + 13), zi);  // canonical: y -+ x are stored canonical
+    // 2d x y stays a lazy product (< p + 2^354): te377.hpp madd_affine takes it as a factor or subtracts it limb-wise from 2p
+    const Fp::El ymx = Fp::sub(y, x), ypx = Fp::add(y, x), kt = Fp::mul_lz(Fp::mul_lz(x, y), Fp::from_const(G1Consts::TE_2D));
     uint32_t o[TeAffBase::REC_WORDS];
     put13(o, ymx);
     put13(o + 13, ypx);

@@ -32,7 +32,8 @@ __device__ __forceinline__ uint32_t key_range(uint32_t key, uint32_t s) {
 // Only windows [wb, wb + wc) are written (window sharding); the carry chain always runs over
 // all 16.  A final carry (scalar >= 2^255 - 2^239) sets *err, as cuzk/utils.ts:95-98 throws.
 __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n,
-                                                   uint32_t wb, uint32_t wc, int* __restrict__ err, uint32_t* __restrict__ top_key_max) {
+                                                   uint32_t wb, uint32_t wc, int* __restrict__ err, uint32_t* __restrict__ top_key_max, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   // top_key_max (may be null): largest key of window 15, the one window that scalars below a 253-bit modulus leave
   // mostly empty; see win_shift.  One LDS atomic per thread at worst, one global atomic per block.
   __shared__ uint32_t wmax;

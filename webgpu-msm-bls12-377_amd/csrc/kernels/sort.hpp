@@ -45,7 +45,8 @@ __device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ dg, 
 }
 
 __global__ void __launch_bounds__(1024) k_range_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts /* [ws][r][c] */,
-                                                      uint64_t n, uint32_t chunks, uint64_t per_chunk, const uint32_t* __restrict__ key_max) {
+                                                      uint64_t n, uint32_t chunks, uint64_t per_chunk, const uint32_t* __restrict__ key_max, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t cnt[NRANGE];
   const uint32_t c = blockIdx.x, ws = blockIdx.y, tid = threadIdx.x;
   const uint32_t shift = win_shift(key_max[ws]);
@@ -64,7 +65,8 @@ __global__ void __launch_bounds__(1024) k_range_count(const uint16_t* __restrict
 
 // Block per window slot, thread per range: region_base[r] = elements in smaller ranges;
 // counts[ws][r][c] becomes the write offset of chunk c inside region r (absolute).
-__global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_base, uint32_t chunks) {
+__global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_base, uint32_t chunks, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t part[NRANGE];
   const uint32_t ws = blockIdx.x, r = threadIdx.x;
   uint32_t* cr = counts + ((size_t)ws * NRANGE + r) * chunks;
@@ -99,7 +101,8 @@ __global__ void __launch_bounds__(NRANGE) k_range_scan(uint32_t* __restrict__ co
 constexpr uint32_t PT_TILE = 8192;  // 8 digits (one 16-byte load) per thread; 64 KB of staging: two workgroups per CU
 __global__ void __launch_bounds__(1024) k_partition_staged(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
                                                            SortElem* __restrict__ temp, uint64_t n, uint32_t chunks, uint64_t per_chunk,
-                                                           const uint32_t* __restrict__ key_max) {
+                                                           const uint32_t* __restrict__ key_max, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t cur[NRANGE];     // this workgroup's write cursor in every range's region
   __shared__ uint32_t cnt[NRANGE];     // elements of the tile per range
   __shared__ uint32_t toff[NRANGE];    // first slot of the range in the staged tile
@@ -200,7 +203,8 @@ constexpr uint32_t LS_REG = LS_CACHE / 256;  // elements per thread
 template <bool CH>
 __global__ void __launch_bounds__(256) k_local_sort_lds(const SortElem* __restrict__ temp, const uint32_t* __restrict__ region_base,
                                                         uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ val_idx, uint64_t n,
-                                                        const uint32_t* __restrict__ key_max, uint32_t NR, uint32_t NBK, ChunkCuts cuts) {
+                                                        const uint32_t* __restrict__ key_max, uint32_t NR, uint32_t NBK, ChunkCuts cuts, uint32_t prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   // NR ranges per window over keys 0 .. NBK (256 x 2^15 on the main path; 4096 x 2^19, one window, no key_max, for the
   // wide windows of kernels/wide.hpp); the last range also owns key NBK.
   constexpr uint32_t MAXK = CH ? MAX_UPLOAD_CHUNKS : 1;

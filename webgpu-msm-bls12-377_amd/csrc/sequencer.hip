@@ -164,10 +164,10 @@ int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, con
   if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   if (prev_window_records)
     hipLaunchKernelGGL(k_affine_up<AffDoublingSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffDoublingSource{prev_window_records, ctx->table_window_bits}, n,
-                       ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
+                       ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2, ctx->conv_wave_prio);
   else
     hipLaunchKernelGGL(k_affine_up<AffWireSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffWireSource{d_raw}, n, ctx->d_aff_stash, ctx->d_aff_trees,
-                       ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2);
+                       ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2, ctx->conv_wave_prio);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->aff_up_done, ctx->stream2));
   if (ctx->tail_threads > 1 && nblk >= 32) ctx->tail_pool.prewake(ctx->aff_prewake_us, std::min(ctx->tail_threads, TailPool::WORKERS + 1) - 1);
@@ -200,7 +200,7 @@ int affine_convert_finish(msm377_ctx* ctx, uint32_t* d_records_out, uint64_t n, 
   }
   // The way down starts as soon as the host has inverted the block products, beside whatever the sort is doing (letting
   // it wait for the sort was measured both ways in round 2: 2^20 2.62 -> 2.59 ms, 2^22 10.39 -> 10.21 without the wait).
-  hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out);
+  hipLaunchKernelGGL(k_affine_down, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, n, ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_inv, d_records_out, ctx->conv_wave_prio);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing == 1) (void)hipEventRecord(ctx->ev[0][MSM377_STAGE_CONVERT][1], ctx->stream2);
   HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->stream2));
@@ -272,6 +272,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   const uint32_t wc = pv.wc, part = pv.part;
   const uint32_t L = ph.bucket_log, NB = 1u << L;  // this call's bucket geometry (shadows the main path's constant)
   const RowView rv{ph.cuts.k, ph.chunk};
+  const uint32_t wprio = ctx->front_wave_prio;  // s_setprio in the decompose / sort / work-list kernels
   const uint32_t RP = (NB + 1) * rv.k + 1;  // row_ptr entries per window slot (NB + 2 for plain rows)
   const bool wide = ph.wide;
   const bool narrow = !wide && ph.cbits != MSM377_WINDOW_BITS;
@@ -318,7 +319,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     else if (glv)
       hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n_scalars, pv.wb, wc, d_err);
     else
-      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err, top_key_max);
+      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err, top_key_max, wprio);
     HIP_TRY(ctx, hipGetLastError());
   }
 
@@ -340,7 +341,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, tot, region_base);
     hipLaunchKernelGGL(k_wide_offsets, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, region_base, chunks);
     hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk, (uint32_t)n, (uint32_t)ph.table_stride);
-    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB, ChunkCuts{});
+    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB, ChunkCuts{}, wprio);
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   } else if (narrow) {
@@ -354,16 +355,16 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     const uint64_t want = (n + 4095) / 4096;  // at least ~4096 elements per block
     if (chunks > want) chunks = (uint32_t)(want ? want : 1);
     const uint64_t per_chunk = (n + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, n, chunks, per_chunk, key_max);
+    hipLaunchKernelGGL(k_range_count, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, n, chunks, per_chunk, key_max, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, range_counts, region_base, chunks);
+    hipLaunchKernelGGL(k_range_scan, dim3(wc), dim3(NRANGE), 0, st, range_counts, region_base, chunks, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_partition_staged, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk, key_max);
+    hipLaunchKernelGGL(k_partition_staged, dim3(chunks, wc), dim3(1024), 0, st, digits, range_counts, sort_temp, n, chunks, per_chunk, key_max, wprio);
     HIP_TRY(ctx, hipGetLastError());
     if (rv.k > 1)  // rows filed by upload chunk: K sub-row bounds per key
-      hipLaunchKernelGGL(k_local_sort_lds<true>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ph.cuts);
+      hipLaunchKernelGGL(k_local_sort_lds<true>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ph.cuts, wprio);
     else
-      hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ChunkCuts{});
+      hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ChunkCuts{}, wprio);
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   }
@@ -376,11 +377,11 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     uint32_t* cursor = meta + SEG_BINS;
     uint32_t* total = meta + 2 * SEG_BINS;
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
-    hipLaunchKernelGGL(k_work_hist, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, work_hist, row_ovf_base, counters, split_rows, rv);
+    hipLaunchKernelGGL(k_work_hist, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, work_hist, row_ovf_base, counters, split_rows, rv, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total);
+    hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work, rv);
+    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work, rv, wprio);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->before_accumulate) {  // must run before the wait below is queued: the wait binds to the event's latest record
       std::function<int()> f;
