@@ -71,7 +71,7 @@ const char* msm377_last_error(const msm377_ctx* ctx);
 /* compute_msm with host buffers: uploads, runs the pipeline, returns the affine result.
  * Replaces submission.ts:85-327 end to end.  Inputs of 2^18 points and more are uploaded in chunks
  * of points that accumulate into the same buckets, so the transfer overlaps the computation
- * (4.8 ms for 2^20 points from pageable memory, 3.1 ms with the inputs already on the device).
+ * (4.3-4.5 ms for 2^20 points from pageable memory, 2.45-2.55 ms with the inputs already on the device).
  * A context is used by one thread at a time. */
 int msm377_g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]);
 
@@ -89,7 +89,7 @@ int msm377_g1_set_bases(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
 int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n);
 /* The same with precomputed window multiples (BASELINE.json config 5, "precomputed-point reuse"; the reference lists
  * precomputation among its own future improvements, /root/reference README.md:558-563): additionally keeps
- * [2^(16 w)] P_i for all 16 windows (16 n affine records: 2.7 GB at n = 2^20, allocated on demand, ~45 ms once).  Every
+ * [2^(16 w)] P_i for all 16 windows (16 n affine records: 2.7 GB at n = 2^20, allocated on demand, ~38 ms once).  Every
  * window then gathers points that already carry its weight, so the sixteen bucket sets are simply added together on the
  * GPU: ONE bucket reduction, one partial record and a 16-step host tail per MSM instead of 16 and 256.  Results are
  * identical.  In the Weierstrass form (msm377_ctx_set_g1_form 0) this is msm377_g1_set_bases. */
@@ -138,7 +138,8 @@ int msm377_g1_combine_partials(const uint8_t* partials, uint8_t out_xy[96]);
  * calling thread: the decomposition of msm377_g1_combine_partials_ctx / the full-MSM entry points, checkable without a
  * GPU (tests/test_host_tail.py).  MSM377_EINVAL for records in Weierstrass form. */
 int msm377_g1_combine_partials_split(const uint8_t* partials, uint32_t pieces, uint8_t out_xy[96]);
-/* The same on the context's tail threads (four Horner chains, as inside msm377_g1_msm): 0.12 instead of 0.18 ms. */
+/* The same on the context's tail threads (the Horner chain cut into up to eight balanced pieces, as inside msm377_g1_msm:
+ * MSM377_TAIL_THREADS, default 6): 0.08 instead of 0.14 ms.  MSM377_EHIP if a helper thread does not answer in time. */
 int msm377_g1_combine_partials_ctx(msm377_ctx* ctx, const uint8_t* partials, uint8_t out_xy[96]);
 
 /* Point sharding, the other partitioning of a multi-GPU run (SURVEY.md section 8e names it as the fallback): rank g runs a
@@ -210,17 +211,21 @@ int msm377_g1_xyzz_to_affine(const uint32_t xyzz[52], uint8_t out_xy[96]);
 int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
 
 /* Internal coordinate system of the G1 full-MSM entry points (msm, msm_device, set_bases + fixed_base*); results
- * are identical.  form 1 (default): the twisted Edwards form of BLS12-377 G1 (csrc/te377.hpp) -- 8 field products
- * per bucket addition instead of 10, no case distinctions; inputs that hit an exceptional case of its addition law
- * (only possible with points outside the prime-order subgroup) rerun in form 0 automatically.  form 0: short
- * Weierstrass XYZZ coordinates behind the GLV front end selected by msm377_ctx_set_glv; the stage read-backs and
- * the window-partials entry points always use it. */
+ * are identical.  form 1 (default): the twisted Edwards form of BLS12-377 G1 (csrc/te377.hpp) -- 7 field products per
+ * bucket addition on affine base records (inputs of 2^20 points and more, resident tables), 8 on projective ones,
+ * instead of the 10 of form 0, no case distinctions; inputs that hit an exceptional case of its addition law (only
+ * possible with points outside the prime-order subgroup) rerun in form 0 automatically.  form 0: short Weierstrass
+ * XYZZ coordinates behind the GLV front end selected by msm377_ctx_set_glv.  The window-partials entry points follow
+ * the same setting and tag their records with the form they are in (form 1: twisted Edwards records; a shard that hit
+ * an exceptional case, or form 0: Weierstrass records); the stage read-backs report theirs (msm377_ctx_get_stage_form). */
 int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form);
 
 /* Small inputs: G1 full-MSM calls of at most `max_points` points (default and at most 2^16; 0 = never) run with
- * 11-bit windows -- 23 windows of 2 048 buckets instead of 16 of 32 768: 0.24-0.56 instead of 0.53-0.60 ms -- the
+ * 11-bit windows -- 23 windows of 2 048 buckets instead of 16 of 32 768: 0.25-0.56 instead of 0.52-0.60 ms -- the
  * counterpart of the reference's switch to narrower windows for small inputs (src/submission/submission.ts:97: 4-bit
- * below 65 536 points).  Same results, same error conditions; scalars of 2^253 and more rerun on the 16-bit path. */
+ * below 65 536 points).  Same results, and the error condition of the 16-bit recode for every input size (the reference's own
+ * 4-bit branch rejects more NON-canonical scalars, k > 0x777...7; every k < r passes both); scalars of 2^253 and more rerun
+ * on the 16-bit path. */
 int msm377_ctx_set_narrow_max(msm377_ctx* ctx, uint64_t max_points);
 
 /* How often this context had to rerun (part of) a call on the Weierstrass path because the twisted Edwards form hit
