@@ -537,17 +537,34 @@ def test_fixed_base_with_precomputed_window_multiples(engine, oracle, window_bit
 
 
 def test_wide_windows_on_skewed_and_larger_inputs(engine, oracle):
-    """The 20-bit-window table at a size where every sort path runs (regions longer than the LDS path holds: the top
-    window's 13-bit digits crowd into the first ranges) and with heavily repeated scalars (rows far longer than a work
-    item, merged from their overflow records)."""
+    """The 20-bit-window table at a size where both partition passes of its sort run over several tiles, and with
+    heavily repeated scalars (rows far longer than a work item, merged from their overflow records; sort regions
+    longer than the LDS path holds)."""
     n = 40000
     pts, ks = seeded_inputs(oracle, n, 77)
     engine.set_precompute_window(20)
     engine.set_bases_precomputed(pts)
-    assert engine.msm_fixed_base(ks) == util.oracle_msm(oracle, pts, ks)
+    want = util.oracle_msm(oracle, pts, ks)
+    assert engine.msm_fixed_base(ks) == want
     few = R.rand_scalars(5, 3)
     skew = R.encode_scalars([few[i % 3] for i in range(n)])
     assert engine.msm_fixed_base(skew) == util.oracle_msm(oracle, pts, skew)
+    # The top window of the table holds 19 bits (6 x 20 + 7 x 19 = 253): scalars of 2^253 and more rerun on the
+    # 16-window path over the table's window 0 -- alone, and as one element of a batch; the largest scalar whose top
+    # digit still fits (2^253 exactly lands on key 2^19) stays on the wide path.
+    ks_int = R.decode_scalars(ks)
+    big = list(ks_int)
+    big[7], big[n - 1] = (1 << 254) + 12345, (1 << 253) + 1
+    big_b = R.encode_scalars(big)
+    want_big = util.oracle_msm(oracle, pts, big_b)
+    assert engine.msm_fixed_base(big_b) == want_big
+    edge = list(ks_int)
+    edge[3], edge[4] = 1 << 253, (1 << 253) - 1
+    edge_b = R.encode_scalars(edge)
+    want_edge = util.oracle_msm(oracle, pts, edge_b)
+    assert engine.msm_fixed_base(edge_b) == want_edge
+    d_s = dev(ks + big_b + edge_b)
+    assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 3) == [want, want_big, want_edge]
     engine.set_precompute_window(16)
     engine.set_bases(pts[:96])  # drops the table
 

@@ -1,5 +1,6 @@
 """Randomized parity soak (not part of the test suite): sizes 1..100003, uniform / short / skewed / near-r scalars,
-all three internal paths, host (chunked upload forced from 3000 points), device and fixed-base entry points, against
+all three internal paths, host (chunked upload forced from 3000 points, both schedules), device, fixed-base and
+precomputed-table (16- and 20-bit windows) entry points, against
 the CPU oracle.  Runs for ~150 s; exit code 1 on any mismatch."""
 import os, sys, random, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -9,6 +10,10 @@ import webgpu_msm_bls12_377_amd as msm
 import util, pyref as R
 oracle = util.load_oracle()
 eng = msm.MsmEngine(1 << 17)
+os.environ.update({"MSM377_UPLOAD_SORT_ONCE": "1", "MSM377_UPLOAD_CHUNKS": "6", "MSM377_UPLOAD_SPLIT": "12"})
+eng_once = msm.MsmEngine(1 << 17)
+for k in ("MSM377_UPLOAD_SORT_ONCE", "MSM377_UPLOAD_CHUNKS", "MSM377_UPLOAD_SPLIT"):
+    del os.environ[k]
 rnd = random.Random(20261004)
 t0 = time.time(); bad = 0; cases = 0
 while time.time() - t0 < 150:
@@ -39,6 +44,14 @@ while time.time() - t0 < 150:
     eng.set_bases(pts)
     if eng.msm_fixed_base(ks) != exp:
         bad += 1; print("MISMATCH fixed", n, seed, mode, flush=True)
+    for bits in (16, 20):  # precomputed window multiples: 16 windows folded on the GPU / 13 wide windows over one bucket set
+        eng.set_precompute_window(bits)
+        eng.set_bases_precomputed(pts)
+        if eng.msm_fixed_base(ks) != exp:
+            bad += 1; print("MISMATCH precomputed", bits, n, seed, mode, flush=True)
+    eng.set_precompute_window(16)
+    if eng_once.msm(pts, ks) != exp:  # host buffers, sorted once (MSM377_UPLOAD_SORT_ONCE=1), 7 chunks
+        bad += 1; print("MISMATCH sort-once upload", n, seed, mode, flush=True)
     cases += 1
 print("soak: %d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)

@@ -73,9 +73,14 @@ constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running pro
 inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POINTS - 1) / AFF_BLOCK_POINTS); }
 
 // ---- wide windows over a precomputed table (kernels/wide.hpp) ----
-constexpr uint32_t WIDE_BITS = MSM377_WIDE_WINDOW_BITS;  // signed 20-bit digits
+constexpr uint32_t WIDE_BITS = MSM377_WIDE_WINDOW_BITS;  // the widest window: signed 20-bit digits
 constexpr uint32_t WIDE_LOG = 19;        // 2^19 buckets, one set for all windows
-constexpr uint32_t WIDE_WINDOWS = 13;    // ceil(256 / 20); windows of the table: [2^(20 w)] P_i
+constexpr uint32_t WIDE_WINDOWS = 13;    // windows of the table: [2^(wide_offset(w))] P_i
+// Six 20-bit windows, then seven 19-bit ones: 6 x 20 + 7 x 19 = 253 bits, every window fills its key range (kernels/wide.hpp).
+constexpr uint32_t WIDE_FULL = 6;
+constexpr uint32_t wide_width(uint32_t w) { return w < WIDE_FULL ? WIDE_BITS : WIDE_BITS - 1; }
+constexpr uint32_t wide_offset(uint32_t w) { return w <= WIDE_FULL ? WIDE_BITS * w : WIDE_BITS * WIDE_FULL + (WIDE_BITS - 1) * (w - WIDE_FULL); }
+static_assert(wide_offset(WIDE_WINDOWS - 1) == 234 && wide_offset(WIDE_WINDOWS - 1) + wide_width(WIDE_WINDOWS - 1) == 253, "the windows cover a 253-bit scalar");
 constexpr uint32_t WIDE_NRANGE = 4096;   // coarse sort ranges of KRANGE = 128 keys
 constexpr uint32_t WIDE_POINTS = WIDE_LOG + 1;  // partial points of the single window record: bucket sum + 19 bit planes
 static_assert((1u << WIDE_LOG) == WIDE_NRANGE * KRANGE, "ranges of KRANGE keys cover the wide bucket set");

@@ -100,7 +100,8 @@ struct msm377_ctx {
   uint32_t table_windows = 0;         // windows the allocated table holds (16, or WIDE_WINDOWS)
   int precomp_bits = MSM377_WINDOW_BITS;  // window width msm377_g1_set_bases_precomputed builds its next table for: 16 or 20 (msm377_ctx_set_precompute_window, MSM377_PRECOMP_BITS)
   uint32_t* d_wide_digits = nullptr;  // wide windows: 13 x n u32 biased 20-bit digits, the flat list the sort reads
-  uint32_t* d_wide_counts = nullptr;  // wide windows: MAX_SORT_BLOCKS x 4096 per-chunk range counts, then 4096 range totals
+  SortElem* d_wide_temp = nullptr;    // wide windows: output of the second partition pass (the first one writes d_sort_temp)
+  uint32_t* d_wide_counts = nullptr;  // wide windows: the sort's counters and offsets (kernels/wide.hpp WC_*)
   uint32_t* d_aff_stash = nullptr;    // cap x 52 words: N1, N2, Z, running product per point (k_affine_up -> k_affine_down)
   uint32_t* d_aff_trees = nullptr;    // one product tree (2 x 256 nodes x 13 words) per AFF_BLOCK_POINTS points
   uint32_t* h_aff_prod = nullptr;     // pinned + coherent host memory the kernels access in place (dm_* = its device address)
@@ -110,7 +111,8 @@ struct msm377_ctx {
   uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
   hipEvent_t aff_up_done = nullptr;
   hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
-  uint32_t table_window_bits = MSM377_WINDOW_BITS;  // doublings between two windows of a precomputed table (AffDoublingSource)
+  uint32_t table_window_bits = MSM377_WINDOW_BITS;  // window width of the resident precomputed table: 16, or WIDE_BITS (six 20-bit + seven 19-bit windows)
+  uint32_t table_doublings = MSM377_WINDOW_BITS;    // doublings from the previous window's multiple to the one being built (AffDoublingSource)
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
   bool te_affine_msm = true;          // MSM377_TE_AFFINE_MSM=0: msm377_g1_msm_device keeps projective records (A/B knob)
   // Below this the batched conversion does not pay: it costs ~9 more products per point than the projective record and

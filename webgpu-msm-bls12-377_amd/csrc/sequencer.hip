@@ -163,7 +163,7 @@ int affine_convert_begin(msm377_ctx* ctx, const uint32_t* d_raw, uint64_t n, con
   __atomic_store_n(ctx->h_aff_flag, 0u, __ATOMIC_RELEASE);
   if (clear_err) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, ctx->stream2, (uint32_t*)(ctx->d_err + 2), 1u, (uint32_t*)nullptr, 0u);
   if (prev_window_records)
-    hipLaunchKernelGGL(k_affine_up<AffDoublingSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffDoublingSource{prev_window_records, ctx->table_window_bits}, n,
+    hipLaunchKernelGGL(k_affine_up<AffDoublingSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffDoublingSource{prev_window_records, ctx->table_doublings}, n,
                        ctx->d_aff_stash, ctx->d_aff_trees, ctx->dm_aff_prod, ctx->dm_aff_flag, ctx->d_aff_count, ctx->d_err + 2, ctx->conv_wave_prio);
   else
     hipLaunchKernelGGL(k_affine_up<AffWireSource>, dim3(nblk), dim3(AFF_THREADS), 0, ctx->stream2, AffWireSource{d_raw}, n, ctx->d_aff_stash, ctx->d_aff_trees,
@@ -249,6 +249,7 @@ struct Phase {
   // Wide windows over a precomputed table (kernels/wide.hpp): `table` holds [2^(20 w)] P_i for 13 windows, the call has
   // ONE window slot of 2^19 buckets fed by the flat list of 13 n digits (cbits = WIDE_BITS, bucket_log = WIDE_LOG).
   bool wide = false;
+  const uint32_t* bases_override = nullptr;  // base records of the call if not ctx->d_bases (the wide table's window 0 = the plain affine records)
   // Points that arrive in chunks (run_sorted_upload): ONE decomposition and sort of all scalars files every row's entries
   // by chunk (`cuts`), then each chunk's accumulation phase walks its own sub-rows (`chunk`) once its points are on the
   // device.  sort / accumulate select which half of the front phase a call enqueues.
@@ -293,7 +294,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   uint32_t* split_rows = ctx->d_split_rows + (size_t)pv.ws0 * NB;
   WorkItem* work = ctx->d_work + pv.work_off;
   uint32_t* ovf = ctx->d_ovf + pv.ovf_off * CV::BKT_WORDS;
-  const uint32_t* bases = ph.table ? ph.table : ctx->d_bases + ph.base_first * BP::REC_WORDS;
+  const uint32_t* bases = ph.table ? ph.table : ph.bases_override ? ph.bases_override : ctx->d_bases + ph.base_first * BP::REC_WORDS;
   uint32_t* meta_block = ctx->d_work_meta + (size_t)part * META_BLOCK_WORDS;  // [work-list counters | key_max[16]]
   uint32_t* key_max = meta_block + (2 * SEG_BINS + 4);
   if (ph.front) {
@@ -323,25 +324,17 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
   }
 
-  if (wide) {  // one counting sort of the 13 n entries by key: 4096 ranges, then k_local_sort_lds per range
-    // (Two radix-64 passes with the tile-staged scatter of the main path instead of one pass into 4096 streams: sort stage
-    // 0.33 -> 0.62 ms at 2^20.  The top window's 13-bit digits put a twelfth of all entries into ONE coarse region, whose
-    // four workgroups then ran six times longer than the rest; with that evened out the two passes still cost what the
-    // one pass costs, profiles/r03_final/wide_two_pass_dropped.txt.)
+  if (wide) {  // the 13 n entries into 4096 fine ranges: two staged partition passes per window (kernels/wide.hpp), then k_local_sort_lds
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
-    const uint64_t N = entries;
-    uint32_t chunks = MAX_SORT_BLOCKS;
-    const uint64_t want = (N + 8191) / 8192;
-    if (chunks > want) chunks = (uint32_t)(want ? want : 1);
-    const uint64_t per_chunk = ((N + chunks - 1) / chunks + 3) & ~3ull;  // whole 16-byte groups of digits
-    uint32_t* counts = ctx->d_wide_counts;
-    uint32_t* tot = counts + (size_t)MAX_SORT_BLOCKS * WIDE_NRANGE;
-    hipLaunchKernelGGL(k_wide_count, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, N, per_chunk);
-    hipLaunchKernelGGL(k_wide_total, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, tot, chunks);
-    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, tot, region_base);
-    hipLaunchKernelGGL(k_wide_offsets, dim3(WIDE_NRANGE / 256), dim3(256), 0, st, counts, region_base, chunks);
-    hipLaunchKernelGGL(k_wide_partition, dim3(chunks), dim3(1024), 0, st, ctx->d_wide_digits, counts, sort_temp, N, per_chunk, (uint32_t)n, (uint32_t)ph.table_stride);
-    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, N, (const uint32_t*)nullptr, WIDE_NRANGE, NB, ChunkCuts{}, wprio);
+    uint32_t* wc = ctx->d_wide_counts;
+    hipLaunchKernelGGL(k_wide_count, dim3(WS_CHUNKS, WIDE_WINDOWS), dim3(1024), 0, st, (const uint32_t*)ctx->d_wide_digits, wc, n);
+    hipLaunchKernelGGL(k_wide_sums, dim3(WIDE_NRANGE / 256, WIDE_WINDOWS), dim3(256), 0, st, wc);
+    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, st, wc, region_base);
+    hipLaunchKernelGGL(k_wide_offsets1, dim3(WIDE_WINDOWS), dim3(WS_COARSE), 0, st, wc, n);
+    hipLaunchKernelGGL(k_wide_part1, dim3(WS_CHUNKS, WIDE_WINDOWS), dim3(1024), 0, st, (const uint32_t*)ctx->d_wide_digits, (const uint32_t*)wc, sort_temp, n, (uint32_t)ph.table_stride);
+    hipLaunchKernelGGL(k_wide_part2, dim3(WS_COARSE, WIDE_WINDOWS), dim3(1024), 0, st, (const SortElem*)sort_temp, (const uint32_t*)wc, ctx->d_wide_temp);
+    hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, (const SortElem*)ctx->d_wide_temp, region_base, row_ptr, val_idx, entries,
+                       (const uint32_t*)nullptr, WIDE_NRANGE, NB, ChunkCuts{}, wprio);
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   } else if (narrow) {
@@ -664,7 +657,8 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
     // Small inputs: narrow windows (k_decompose_narrow); the window-indexed buffers are sized for them too
     // (msm377_ctx_create: wcap).  Stage read-backs describe the 16-bit geometry.
     bool narrow = form != TABLE_TE_PRECOMP && n <= ctx->narrow_max_points && n <= SMALL_SORT_MAX && !ctx->capture;
-    const bool wide = form == TABLE_TE_PRECOMP && ctx->table_window_bits == WIDE_BITS;
+    bool wide = form == TABLE_TE_PRECOMP && ctx->table_window_bits == WIDE_BITS;
+    bool table0 = false;  // the 16-window path over window 0 of the wide table (= the affine records of the points themselves)
     for (;;) {
       uint32_t windows = MSM377_NUM_WINDOWS;
       int cbits = MSM377_WINDOW_BITS, planes = MSM377_WINDOW_BITS - 1;
@@ -699,6 +693,15 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
         narrow = false;
         continue;
       }
+      if (wide && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // likewise: its top window holds 19 bits
+        wide = false;
+        table0 = true;
+        ph.wide = false;
+        ph.table = nullptr;
+        ph.table_stride = 0;  // every window slot gathers from the same records
+        ph.bases_override = ctx->d_table;
+        continue;
+      }
       if (ctx->h_err[0] & ERR_TE_ANY) {
         note_fallback(ctx, (uint32_t)(ctx->h_err[0] & ERR_TE_ANY));
         return RC_TE_FALLBACK;
@@ -706,7 +709,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
-      const int tr = form == TABLE_TE_PRECOMP ? (teh_combine(ctx->h_partials, 1, out_xy, cbits, planes) ? TAIL_EXCEPTIONAL : TAIL_OK)
+      const int tr = form == TABLE_TE_PRECOMP && !table0 ? (teh_combine(ctx->h_partials, 1, out_xy, cbits, planes) ? TAIL_EXCEPTIONAL : TAIL_OK)
                                               : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes);
       time_tail(ctx, t0);
       if (tr < 0) return tr;
@@ -1107,11 +1110,12 @@ int ed_generate_bases_device(msm377_ctx* ctx, uint64_t seed, uint64_t n, void* d
 
 // The precomputed-window table and its wide-window work buffers (allocated on demand, 2.2-2.7 GB at 2^20 points).
 void free_table(msm377_ctx* ctx) {
-  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts})
+  for (void* p : {(void*)ctx->d_table, (void*)ctx->d_wide_digits, (void*)ctx->d_wide_counts, (void*)ctx->d_wide_temp})
     if (p) (void)hipFree(p);
   ctx->d_table = nullptr;
   ctx->d_wide_digits = nullptr;
   ctx->d_wide_counts = nullptr;
+  ctx->d_wide_temp = nullptr;
   ctx->table_cap = 0;
   ctx->table_windows = 0;
 }
@@ -1165,7 +1169,8 @@ int g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint6
     bool ok = hipMalloc((void**)&ctx->d_table, (size_t)windows * n * TeAffBase::REC_WORDS * 4) == hipSuccess;
     if (ok && wide)
       ok = hipMalloc((void**)&ctx->d_wide_digits, (size_t)WIDE_WINDOWS * n * 4) == hipSuccess &&
-           hipMalloc((void**)&ctx->d_wide_counts, ((size_t)MAX_SORT_BLOCKS + 1) * WIDE_NRANGE * 4) == hipSuccess;
+           hipMalloc((void**)&ctx->d_wide_temp, (size_t)WIDE_WINDOWS * n * sizeof(SortElem)) == hipSuccess &&
+           hipMalloc((void**)&ctx->d_wide_counts, WC_WORDS * 4) == hipSuccess;
     if (!ok) {
       free_table(ctx);
       (void)hipGetLastError();
@@ -1175,8 +1180,13 @@ int g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points, uint6
     ctx->table_cap = n;
     ctx->table_windows = windows;
   }
+  if (wide && (uint64_t)WIDE_WINDOWS * n >= (1ull << 31)) {
+    ctx->err = "precomputed-window table: too many points for 20-bit windows (13 n must stay below 2^31)";
+    return MSM377_EINVAL;
+  }
   ctx->table_window_bits = wide ? WIDE_BITS : (uint32_t)MSM377_WINDOW_BITS;
   for (uint32_t w = 0; w < windows && rc == MSM377_OK; w++) {
+    ctx->table_doublings = !wide ? (uint32_t)MSM377_WINDOW_BITS : w ? wide_width(w - 1) : 0u;  // from the previous window's multiple to this one's
     uint32_t* mine = ctx->d_table + (size_t)w * n * TeAffBase::REC_WORDS;
     rc = affine_convert_begin(ctx, (const uint32_t*)d_points, n, w == 0 ? nullptr : mine - (size_t)n * TeAffBase::REC_WORDS, w == 0);
     if (rc == MSM377_OK) rc = affine_convert_finish(ctx, mine, n);
@@ -1252,6 +1262,7 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
   const int tail_cbits = wide ? (int)WIDE_BITS : 16, tail_planes = wide ? (int)WIDE_LOG : 15;
   const int W_tail = form == TABLE_TE_PRECOMP ? 1 : (int)W;  // window records the host combines per MSM
   std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
+  std::vector<uint32_t> redo_wide;  // elements with a scalar of 2^253 and more on the wide table: rerun one by one (g1_table_msm falls back)
   bool te_fallback = false;
   // Software pipeline over the batch: while the GPU runs MSM b, the host finishes MSM b-1
   // (Horner + inversion on the other slot's partial records).
@@ -1272,6 +1283,10 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
       if (te_fallback) continue;
       if (glv && (ctx->h_err[slot] & ERR_GLV_RANGE)) {
         redo.push_back(b - 1);
+        continue;
+      }
+      if (wide && (ctx->h_err[slot] & ERR_NARROW_RANGE) && !(ctx->h_err[slot] & ERR_SCALAR)) {
+        redo_wide.push_back(b - 1);
         continue;
       }
       rc = finish_windows(ctx, slot);
@@ -1296,6 +1311,15 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
   }
   for (uint32_t b : redo) {
     rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, TABLE_XYZZ, out_xy + (size_t)96 * b);
+    if (rc) return rc;
+  }
+  for (uint32_t b : redo_wide) {
+    rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, TABLE_TE_PRECOMP, out_xy + (size_t)96 * b);
+    if (rc == RC_TE_FALLBACK) {
+      rc = resident_table_to_weierstrass(ctx);
+      if (rc) return rc;
+      return g1_msm_fixed_base_batch_device(ctx, d_scalars, n, batch, out_xy);
+    }
     if (rc) return rc;
   }
   return MSM377_OK;
