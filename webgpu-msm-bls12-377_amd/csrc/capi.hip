@@ -75,6 +75,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_NARROW_QUAD_ACC")) ctx->narrow_quad_acc = atoi(e);
   if (const char* e = getenv("MSM377_COOP_THREADS")) ctx->coop_threads = (uint32_t)atoi(e);
   if (const char* e = getenv("MSM377_NARROW_TAIL_FROM")) ctx->narrow_tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
+  if (const char* e = getenv("MSM377_TWIN_BATCH")) ctx->twin_batches = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_FROM")) ctx->tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
   const uint64_t cap = max_points;
   // The main stream outranks the side stream: the base conversion (VALU-heavy, ~0.2 ms) only has to finish before
@@ -151,6 +152,12 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  if (ctx->twin) {  // it owns everything but the table it borrows during a batch call
+    ctx->twin->d_bases = nullptr;
+    ctx->twin->d_table = nullptr;
+    msm377_ctx_destroy(ctx->twin);
+    ctx->twin = nullptr;
+  }
   void* bufs[] = {ctx->d_raw_points, ctx->d_raw_scalars, ctx->d_bases, ctx->d_digits, ctx->d_range_counts, ctx->d_region_base, ctx->d_sort_temp,
                   ctx->d_row_ptr, ctx->d_val_idx, ctx->d_buckets, ctx->d_buckets_snap, ctx->d_partials, ctx->d_work, ctx->d_work_meta, ctx->d_row_ovf_base, ctx->d_split_rows, ctx->d_ovf, ctx->d_err, ctx->d_aff_stash, ctx->d_aff_trees, ctx->d_aff_count, ctx->d_out_count, ctx->d_table, ctx->d_wide_digits, ctx->d_wide_counts, ctx->d_wide_temp, ctx->d_row_ptr_chunks};
   for (void* p : bufs)

@@ -198,6 +198,11 @@ struct msm377_ctx {
   // 2^10 0.64 / 0.46, 2^13 0.67 / 0.53, 2^14 0.68 / 0.51, 2^15 0.73 / 0.60, 2^16 0.74 / 0.71 (first version); at the end of
   // round 2: 2^16 0.605 / 0.56 (its bucket reduction 0.28 / 0.10 ms, its accumulation kernel 0.14 / 0.18), hence 2^16.
   uint64_t narrow_max_points = 1ull << 16;
+  // Batches on two sets of streams and buffers (sequencer.hip twin_prepare)
+  msm377_ctx* twin = nullptr;   // owned; borrows d_bases / d_table for the length of a batch call
+  bool twin_batches = true;     // MSM377_TWIN_BATCH=0: batches run on this context alone
+  bool twin_failed = false;
+  uint64_t wide_cap = 0;        // points the twin's wide-window buffers hold
   uint64_t fallback_count = 0;  // reruns on the Weierstrass path after an exceptional case of the Edwards law
   uint32_t fallback_mask = 0;   // MSM377_FB_* bits of the last one
 };

@@ -1231,18 +1231,10 @@ int g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n,
   return g1_table_msm(ctx, (const uint32_t*)d_scalars, n, resident_form(ctx, n), out_xy);
 }
 
-int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy) {
-  if (!out_xy) return MSM377_EINVAL;
-  int rc = check_args(ctx, nullptr, d_scalars, n, false);
-  if (rc) return rc;
-  if (n > ctx->bases_n) {
-    ctx->err = "fixed-base MSM needs g1_set_bases with at least n points first";
-    return MSM377_ESTATE;
-  }
-  if (n == 0) {
-    for (uint32_t b = 0; b < batch; b++) identity_wire(out_xy + (size_t)96 * b);
-    return MSM377_OK;
-  }
+// `batch` MSMs of n scalars each against the table resident in (or lent to, twin_borrow) `ctx`, on ctx's own stream and
+// buffers.  RC_TE_FALLBACK: an exceptional case of the Edwards law; nothing of out_xy is valid then.
+static int fixed_base_batch_share(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy) {
+  int rc = MSM377_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t* sc = (const uint32_t*)d_scalars;
   const int form = resident_form(ctx, n);
@@ -1303,11 +1295,9 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
         g1h_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W, out_xy + (size_t)96 * (b - 1));
     }
   }
-  if (te_fallback) {  // an exceptional case of the Edwards law somewhere in the batch: Weierstrass table, whole batch again
+  if (te_fallback) {  // an exceptional case of the Edwards law somewhere in the batch: the caller rebuilds the table and reruns
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    rc = resident_table_to_weierstrass(ctx);
-    if (rc) return rc;
-    return g1_msm_fixed_base_batch_device(ctx, d_scalars, n, batch, out_xy);
+    return RC_TE_FALLBACK;
   }
   for (uint32_t b : redo) {
     rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, TABLE_XYZZ, out_xy + (size_t)96 * b);
@@ -1315,14 +1305,112 @@ int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint6
   }
   for (uint32_t b : redo_wide) {
     rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, TABLE_TE_PRECOMP, out_xy + (size_t)96 * b);
-    if (rc == RC_TE_FALLBACK) {
-      rc = resident_table_to_weierstrass(ctx);
-      if (rc) return rc;
-      return g1_msm_fixed_base_batch_device(ctx, d_scalars, n, batch, out_xy);
-    }
-    if (rc) return rc;
+    if (rc) return rc;  // RC_TE_FALLBACK included
   }
   return MSM377_OK;
+}
+
+static void twin_return(msm377_ctx* ctx) {
+  msm377_ctx* tw = ctx->twin;
+  if (!tw) return;
+  tw->d_bases = nullptr;
+  tw->d_table = nullptr;
+  tw->bases_n = 0;
+}
+
+// The twin of a context: a second context on the same device -- own streams, work buffers, pinned records -- that BORROWS
+// the resident table for the length of one batch call.  Created with the first batch that is large enough; its cost
+// (the work buffers a second time, ~0.7 GB at 2^20 points) is why small batches do not ask for it.
+constexpr uint32_t TWIN_MIN_BATCH = 4;
+
+static int twin_prepare(msm377_ctx* ctx) {
+  if (!ctx->twin) {
+    if (ctx->twin_failed) return MSM377_ENOMEM;
+    msm377_ctx* tw = nullptr;
+    if (msm377_ctx_create(ctx->device, ctx->cap, &tw) != MSM377_OK) {
+      ctx->twin_failed = true;  // out of memory for a second set: batches run on one
+      (void)hipGetLastError();
+      return MSM377_ENOMEM;
+    }
+    (void)hipFree(tw->d_bases);  // it only ever borrows
+    tw->d_bases = nullptr;
+    (void)hipFree(tw->d_raw_points);
+    tw->d_raw_points = nullptr;
+    tw->twin_batches = false;
+    ctx->twin = tw;
+  }
+  msm377_ctx* tw = ctx->twin;
+  const bool wide = ctx->bases_form == TABLE_TE_PRECOMP && ctx->table_window_bits == WIDE_BITS;
+  if (wide && tw->wide_cap < ctx->bases_n) {
+    for (void* p : {(void*)tw->d_wide_digits, (void*)tw->d_wide_counts, (void*)tw->d_wide_temp})
+      if (p) (void)hipFree(p);
+    tw->d_wide_digits = nullptr, tw->d_wide_counts = nullptr, tw->d_wide_temp = nullptr, tw->wide_cap = 0;
+    const uint64_t n = ctx->bases_n;
+    if (hipMalloc((void**)&tw->d_wide_digits, (size_t)WIDE_WINDOWS * n * 4) != hipSuccess ||
+        hipMalloc((void**)&tw->d_wide_temp, (size_t)WIDE_WINDOWS * n * sizeof(SortElem)) != hipSuccess ||
+        hipMalloc((void**)&tw->d_wide_counts, WC_WORDS * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      return MSM377_ENOMEM;
+    }
+    tw->wide_cap = n;
+  }
+  // lend the table, and the conversion's verdict that travels with it (d_err[2], read by the accumulation kernels)
+  tw->d_bases = ctx->d_bases;
+  tw->d_table = ctx->d_table;
+  tw->bases_n = ctx->bases_n;
+  tw->bases_form = ctx->bases_form;
+  tw->table_window_bits = ctx->table_window_bits;
+  tw->table_windows = ctx->table_windows;
+  tw->seg_plain = ctx->seg_plain, tw->seg_glv = ctx->seg_glv, tw->tail_from = ctx->tail_from;
+  if (hipMemcpyAsync(tw->d_err + 2, ctx->d_err + 2, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    twin_return(ctx);
+    return MSM377_EHIP;
+  }
+  return MSM377_OK;
+}
+
+int g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy) {
+  if (!out_xy) return MSM377_EINVAL;
+  int rc = check_args(ctx, nullptr, d_scalars, n, false);
+  if (rc) return rc;
+  if (n > ctx->bases_n) {
+    ctx->err = "fixed-base MSM needs g1_set_bases with at least n points first";
+    return MSM377_ESTATE;
+  }
+  if (n == 0) {
+    for (uint32_t b = 0; b < batch; b++) identity_wire(out_xy + (size_t)96 * b);
+    return MSM377_OK;
+  }
+  // Batches run as two halves on two sets of streams and buffers (twin_prepare): the low-occupancy ends of one MSM --
+  // the last tree levels and the tail of its reduction, the drain of its accumulation kernel, its memory-bound sort --
+  // fill with the other half's kernels.  Two contexts side by side measured 2.01 -> 1.89 ms per MSM on the 20-bit table
+  // and 2.19 -> 2.09 on the plain one (tools/twin_probe.py, profiles/r03_final/twin_probe.txt).
+  const bool split = batch >= TWIN_MIN_BATCH && ctx->twin_batches && !ctx->timing && !ctx->capture && twin_prepare(ctx) == MSM377_OK;
+  if (!split) {
+    rc = fixed_base_batch_share(ctx, d_scalars, n, batch, out_xy);
+  } else {
+    msm377_ctx* tw = ctx->twin;
+    const uint32_t mine = batch - batch / 2;
+    int rc2 = MSM377_OK;
+    std::thread other([&] { rc2 = fixed_base_batch_share(tw, (const uint32_t*)d_scalars + (size_t)mine * n * 8, n, batch - mine, out_xy + (size_t)96 * mine); });
+    rc = fixed_base_batch_share(ctx, d_scalars, n, mine, out_xy);
+    other.join();
+    twin_return(ctx);
+    if (rc2 && !rc) {  // the first half's error wins; RC_TE_FALLBACK of either half reruns the whole batch
+      rc = rc2;
+      if (rc2 != RC_TE_FALLBACK) ctx->err = tw->err;
+    }
+    if (tw->fallback_count) {
+      ctx->fallback_count += tw->fallback_count;
+      ctx->fallback_mask = tw->fallback_mask;
+      tw->fallback_count = 0;
+    }
+  }
+  if (rc != RC_TE_FALLBACK) return rc;
+  rc = resident_table_to_weierstrass(ctx);  // whole batch again on the Weierstrass table
+  if (rc) return rc;
+  return g1_msm_fixed_base_batch_device(ctx, d_scalars, n, batch, out_xy);
 }
 
 int g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]) {
