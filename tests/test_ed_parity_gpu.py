@@ -121,6 +121,39 @@ def test_host_buffers_upload_in_two_chunks(oracle, monkeypatch):
         eng.close()
 
 
+def test_even_window_geometry_edge_scalars(engine, oracle, monkeypatch):
+    """The top three windows are 15 bits wide (kernels/decompose.hpp k_decompose `even`): digits at their boundaries,
+    carries through them, and scalars that do not fit (the call reruns with sixteen equal windows) -- from device
+    buffers, from host buffers, and through the chunked upload."""
+    s15 = 0x7FFF
+    edge = [
+        s15 << 208, s15 << 223, s15 << 238, (s15 << 208) + (0x8000 << 192), (s15 << 208) + (s15 << 223) + (0x8000 << 192),
+        (s15 << 208) + (s15 << 223) + (s15 << 238) + (0x8000 << 192), (s15 << 238) + (s15 << 223) + (s15 << 208) + 0x7FFF,
+        (1 << 253) - 1, 1 << 253, (1 << 254) + 5, (1 << 223) - 1, 1 << 223, (1 << 238) - 1, 1 << 238, 0, 1, R.ED_SUBGROUP - 1,
+    ]
+    n = len(edge)
+    pts_b = util.oracle_ed_gen_points(oracle, n, 0x1234567, 0x7654321)
+    pts = [(int.from_bytes(pts_b[64 * i : 64 * i + 32], "little"), int.from_bytes(pts_b[64 * i + 32 : 64 * i + 64], "little")) for i in range(n)]
+    small = R.rand_scalars(4, n, R.ED_SUBGROUP)
+    for i, k in enumerate(edge):
+        kk = list(small)
+        kk[i] = k
+        assert engine.ed_msm(pts_b, R.encode_scalars(kk)) == R.ed_encode_result(R.ed_msm_naive(pts, kk)), hex(k)
+    want = R.ed_encode_result(R.ed_msm_naive(pts, edge))
+    assert engine.ed_msm(pts_b, R.encode_scalars(edge)) == want
+    d_p, d_s = dev(pts_b), dev(R.encode_scalars(edge))
+    assert engine.ed_msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == want
+    monkeypatch.setenv("MSM377_UPLOAD_CHUNK_MIN", "100")
+    eng = msm.MsmEngine(1 << 12)
+    try:
+        reps = 8  # 136 points: four chunks
+        ks8 = [k * (r + 1) % (1 << 253) if k < (1 << 253) else k for r in range(reps) for k in edge]
+        assert eng.ed_msm(pts_b * reps, R.encode_scalars(ks8)) == R.ed_encode_result(R.ed_msm_naive(pts * reps, ks8))
+        assert eng.ed_msm(pts_b * reps, R.encode_scalars(small * reps)) == R.ed_encode_result(R.ed_msm_naive(pts * reps, small * reps))
+    finally:
+        eng.close()
+
+
 def test_one_repeated_point_and_opposites(engine):
     """The complete addition law must cover P + P and P + (-P) inside buckets."""
     p = R.ed_mul(R.ED_G, 123456789)

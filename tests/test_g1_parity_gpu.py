@@ -133,6 +133,61 @@ def test_narrow_windows_edge_cases(engine, oracle, golden):
         engine.set_narrow_max()
 
 
+def test_even_window_geometry_edge_cases(engine, oracle, golden):
+    """Whole MSMs on the main path recode scalars into thirteen signed 16-bit windows and three UNSIGNED 15-bit ones
+    (bit offsets 208, 223, 238; kernels/decompose.hpp k_decompose `even`): every golden vector forced onto that path,
+    digits at the boundaries of the short windows (2^15 - 1 with and without a carry coming in, carries running through
+    all three), scalars whose top digit does not fit (2^253 - 2^238 + ... and everything from 2^253 on: the call reruns
+    with sixteen equal windows), the scalar-overflow error unchanged, and the same inputs through a batch."""
+    engine.set_narrow_max(0)
+    try:
+        for name, case in golden.items():
+            if name.startswith("g1_"):
+                assert engine.msm(case["points"], case["scalars"]) == case["expected"], name
+        n = 300
+        pts, ks = seeded_inputs(oracle, n, 4242)
+        pl = R.decode_points(pts)
+        kl = R.decode_scalars(ks)
+        s15 = 0x7FFF
+        edge = [
+            s15 << 208, s15 << 223, s15 << 238,                      # the largest digit of each short window
+            (s15 << 208) + (0x8000 << 192),                          # a carry into window 13 wraps it to 0, carry on
+            (s15 << 208) + (s15 << 223) + (0x8000 << 192),           # ... through window 14 into the top window
+            (s15 << 208) + (s15 << 223) + (s15 << 238) + (0x8000 << 192),  # ... and out of it: does not fit (< 2^253)
+            (s15 << 238) + (s15 << 223) + (s15 << 208) + 0x7FFF,     # largest scalar that fits with no carry at all
+            (1 << 253) - 1, 1 << 253, (1 << 254) + 5,                # from 2^253 on: never fits
+            (1 << 208) - 1, 1 << 208, (1 << 223) - 1, 1 << 223, (1 << 238) - 1, 1 << 238,
+            0x8000 << 192, 0x7FFF << 192, R.R_ORDER - 1, R.R_ORDER - 2, 0, 1,
+        ]
+        fits = lambda k: k < (1 << 253) and not (k >> 238 == s15 and (k >> 223) & s15 == s15 and (k >> 208) & s15 == s15 and (k >> 207) & 1)  # noqa: E731
+        assert [fits(k) for k in edge[3:10]] == [True, True, False, True, False, False, False]
+        base = R.decode_result(util.oracle_msm(oracle, pts, ks))
+        for i, k in enumerate(edge):  # one edge scalar at a time, so that those that fit stay on the even windows
+            kk = list(kl)
+            kk[i] = k
+            exp = R.add(R.add(base, R.neg(R.mul(pl[i], kl[i]))), R.mul(pl[i], k))
+            assert engine.msm(pts, R.encode_scalars(kk)) == R.encode_result(exp), hex(k)
+        kk = list(kl)
+        kk[: len(edge)] = edge
+        want = R.encode_result(R.msm_naive(pl, kk))
+        assert engine.msm(pts, R.encode_scalars(kk)) == want
+        d_p, d_s = dev(pts), dev(R.encode_scalars(kk))
+        assert engine.msm_device(d_p.data_ptr(), d_s.data_ptr(), n) == want
+        engine.set_bases(pts)
+        d_b = dev(ks + R.encode_scalars(kk) + ks + R.encode_scalars(kk) + ks)
+        plain = util.oracle_msm(oracle, pts, ks)
+        assert engine.msm_fixed_base_batch_device(d_b.data_ptr(), n, 5) == [plain, want, plain, want, plain]
+        case = golden["g1_n1_gen"]
+        for bad in ((1 << 256) - 1, (1 << 255) - (1 << 239)):
+            with pytest.raises(msm.MsmError) as e:
+                engine.msm(case["points"], bad.to_bytes(32, "little"))
+            assert e.value.code == -3
+        for ok in (0x7FFF << 240, (1 << 255) - (1 << 239) - (1 << 224)):  # beyond 2^253, below the error threshold
+            assert engine.msm(case["points"], ok.to_bytes(32, "little")) == R.encode_result(R.mul(R.G, ok)), hex(ok)
+    finally:
+        engine.set_narrow_max()
+
+
 def test_2_16_against_reference_sized_oracle(engine, oracle):
     """BASELINE.json configs[0] size: the oracle runs the reference's production parameters
     (16-bit windows, 256 BPR threads) on 2^16 points."""
@@ -670,6 +725,7 @@ def test_point_sharding_on_one_gpu(engine, oracle, world):
         {"MSM377_TAIL_THREADS": "1"},
         {"MSM377_TAIL_THREADS": "8", "MSM377_TAIL_SPIN_US": "0", "MSM377_TAIL_NUMA": "0"},
         {"MSM377_TAIL_THREADS": "3"},
+        {"MSM377_EVEN_WINDOWS": "0", "MSM377_TWIN_BATCH": "0"},  # sixteen equal windows everywhere; batches on one context
         {"MSM377_NARROW_TAIL_FROM": "7", "MSM377_COOP_THREADS": "65536", "MSM377_NARROW_SEG": "32"},
         {"MSM377_NARROW_TAIL_FROM": "1", "MSM377_COOP_THREADS": "100000000"},  # every level on lane quads, everything behind level 0 in one launch
     ],
@@ -727,6 +783,9 @@ def test_host_buffers_upload_in_chunks(oracle, monkeypatch, schedule):
         pts, _ = seeded_inputs(oracle, n, 77)
         ks = R.encode_scalars([R.rand_scalars(5, 1)[0]] * n)  # one bucket per window, split rows in both chunks
         assert eng.msm(pts, ks) == util.oracle_msm(oracle, pts, ks)
+        kb = R.decode_scalars(ks)
+        kb[n - 2] = (1 << 253) + 77  # does not fit the even windows: one rerun in one piece
+        assert eng.msm(pts, R.encode_scalars(kb)) == util.oracle_msm(oracle, pts, R.encode_scalars(kb))
         pl = R.decode_points(pts)[:400]
         pl[333] = (R.P - 1, 0)
         kl = R.rand_scalars(9, 400)

@@ -73,6 +73,10 @@ constexpr uint32_t AFF_STASH_WORDS = 52;  // N1, N2, Z, C (exclusive running pro
 inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POINTS - 1) / AFF_BLOCK_POINTS); }
 
 // ---- wide windows over a precomputed table (kernels/wide.hpp) ----
+// Whole MSMs on the 16-window path: windows 13, 14, 15 are 15 bits wide (kernels/decompose.hpp k_decompose, `even`).
+constexpr uint32_t EVEN_FROM = 13;
+constexpr uint32_t even_offset(uint32_t w) { return 16 * w - (w > EVEN_FROM ? w - EVEN_FROM : 0u); }
+static_assert(even_offset(13) == 208 && even_offset(14) == 223 && even_offset(15) == 238 && even_offset(16) == 253, "13 x 16 + 3 x 15 = 253 bits");
 constexpr uint32_t WIDE_BITS = MSM377_WIDE_WINDOW_BITS;  // the widest window: signed 20-bit digits
 constexpr uint32_t WIDE_LOG = 19;        // 2^19 buckets, one set for all windows
 constexpr uint32_t WIDE_WINDOWS = 13;    // windows of the table: [2^(wide_offset(w))] P_i

@@ -199,6 +199,8 @@ struct msm377_ctx {
   // round 2: 2^16 0.605 / 0.56 (its bucket reduction 0.28 / 0.10 ms, its accumulation kernel 0.14 / 0.18), hence 2^16.
   uint64_t narrow_max_points = 1ull << 16;
   // Batches on two sets of streams and buffers (sequencer.hip twin_prepare)
+  bool even_windows = true;     // MSM377_EVEN_WINDOWS=0: sixteen 16-bit windows on every path (kernels/decompose.hpp k_decompose)
+  bool ed_equal_windows_once = false;  // ed_msm -> ed_msm_device: this call reruns a chunked upload whose scalars did not fit
   msm377_ctx* twin = nullptr;   // owned; borrows d_bases / d_table for the length of a batch call
   bool twin_batches = true;     // MSM377_TWIN_BATCH=0: batches run on this context alone
   bool twin_failed = false;

@@ -331,11 +331,25 @@ inline void g1h_to_wire(const G1H::XYZZ& p, uint8_t out[96]) {
 // front end).  partials layout: [window][point][48 words], point 0 =
 // Sum_w, point 1 + l = Plane_{w,l}.
 // Bit positions [lo, hi) of the chain only (position b = 16 w + l): sum_b 2^(b - lo) record_b.
-inline G1H::XYZZ g1h_horner_bits(const uint32_t* partials, int lo, int hi, uint32_t skip_windows = 0) {
+// Window geometry of the chain (sequencer.hip Phase::even): short_from = 0 -- every window is cbits wide; otherwise the
+// windows from short_from on are one bit shorter (common.hpp even_offset: thirteen 16-bit and three 15-bit windows).
+inline void tail_position(int b, int cbits, int short_from, int& w, int& l) {
+  const int full = cbits * short_from;
+  if (short_from == 0 || b < full) {
+    w = b / cbits, l = b % cbits;
+  } else {
+    w = short_from + (b - full) / (cbits - 1), l = (b - full) % (cbits - 1);
+  }
+}
+inline int tail_positions(int num_windows, int cbits, int short_from) {
+  return cbits * num_windows - (short_from && num_windows > short_from ? num_windows - short_from : 0);
+}
+inline G1H::XYZZ g1h_horner_bits(const uint32_t* partials, int lo, int hi, uint32_t skip_windows = 0, int short_from = 0) {
   G1H::XYZZ acc = G1H::identity();
   for (int b = hi - 1; b >= lo; b--) {
     acc = G1H::dbl(acc);
-    const int w = b >> 4, l = b & 15;
+    int w, l;
+    tail_position(b, 16, short_from, w, l);
     if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
     if (l < 15) acc = G1H::add(acc, g1h_from_record_words(base + (size_t)(1 + l) * 48));
@@ -343,10 +357,12 @@ inline G1H::XYZZ g1h_horner_bits(const uint32_t* partials, int lo, int hi, uint3
   }
   return acc;
 }
-inline G1H::XYZZ g1h_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0) {
-  return g1h_horner_bits(partials, 0, 16 * num_windows, skip_windows);
+inline G1H::XYZZ g1h_horner(const uint32_t* partials, int num_windows, uint32_t skip_windows = 0, int short_from = 0) {
+  return g1h_horner_bits(partials, 0, tail_positions(num_windows, 16, short_from), skip_windows, short_from);
 }
-inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[96]) { g1h_to_wire(g1h_horner(partials, num_windows), out); }
+inline void g1h_combine(const uint32_t* partials, int num_windows, uint8_t out[96], int short_from = 0) {
+  g1h_to_wire(g1h_horner(partials, num_windows, 0, short_from), out);
+}
 
 // ---- G1 tail in twisted Edwards form (csrc/te377.hpp) ----
 struct TeK64 {
@@ -420,11 +436,13 @@ inline bool teh_is_identity(const TeH::Ext& p) { return Fp64::is_zero(p.x) && Fp
 // cbits: distance of two windows in bits (16 on the main path, 11 on the narrow-window path for small inputs);
 // planes: bit planes per window record = log2 of its buckets (15 / 11), all inside the same 16-point record.
 // Bit positions [lo, hi) of the chain only (position b = cbits w + l): sum_b 2^(b - lo) record_b.
-inline TeH::Ext teh_horner_bits(const uint32_t* partials, int lo, int hi, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
+inline TeH::Ext teh_horner_bits(const uint32_t* partials, int lo, int hi, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15,
+                                int short_from = 0) {
   TeH::Ext acc = TeH::identity();
   for (int b = hi - 1; b >= lo; b--) {
     acc = chk.dbl(acc);
-    const int w = b / cbits, l = b % cbits;
+    int w, l;
+    tail_position(b, cbits, short_from, w, l);
     if ((skip_windows >> w) & 1u) continue;
     const uint32_t* base = partials + (size_t)w * 16 * 48;
     // identity points cost nothing: the records of a rank that folded its windows (g1_fold_tagged) are mostly that
@@ -439,8 +457,9 @@ inline TeH::Ext teh_horner_bits(const uint32_t* partials, int lo, int hi, TeChec
   }
   return acc;
 }
-inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15) {
-  return teh_horner_bits(partials, 0, cbits * num_windows, chk, skip_windows, cbits, planes);
+inline TeH::Ext teh_horner(const uint32_t* partials, int num_windows, TeChecked& chk, uint32_t skip_windows = 0, int cbits = 16, int planes = 15,
+                           int short_from = 0) {
+  return teh_horner_bits(partials, 0, tail_positions(num_windows, cbits, short_from), chk, skip_windows, cbits, planes, short_from);
 }
 inline int imin(int a, int b) { return a < b ? a : b; }
 // ---- the tail in pieces (msm377.hip tail_horner_mt runs them on threads) ----
@@ -473,8 +492,8 @@ inline int tail_split(int positions, int chains, int* bounds) {
 
 // One piece: sum of the records of positions [lo, hi) x 2^(position), i.e. its own Horner chain and then `lo` doublings
 // (all but the last without T: nothing reads it before the next doubling).
-inline TeH::Ext teh_tail_piece(const uint32_t* partials, int lo, int hi, TeChecked& chk, int cbits = 16, int planes = 15) {
-  TeH::Ext acc = teh_horner_bits(partials, lo, hi, chk, 0, cbits, planes);
+inline TeH::Ext teh_tail_piece(const uint32_t* partials, int lo, int hi, TeChecked& chk, int cbits = 16, int planes = 15, int short_from = 0) {
+  TeH::Ext acc = teh_horner_bits(partials, lo, hi, chk, 0, cbits, planes, short_from);
   for (int i = 0; i + 1 < lo; i++) acc = chk.dbl_nt(acc);
   if (lo > 0) acc = chk.dbl(acc);
   return acc;
@@ -495,9 +514,9 @@ inline bool teh_combine_split(const uint32_t* partials, int num_windows, uint8_t
 }
 
 // false: done; true: an exceptional case of the law (out untouched).
-inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96], int cbits = 16, int planes = 15) {
+inline bool teh_combine(const uint32_t* partials, int num_windows, uint8_t out[96], int cbits = 16, int planes = 15, int short_from = 0) {
   TeChecked chk;
-  const TeH::Ext r = teh_horner(partials, num_windows, chk, 0, cbits, planes);
+  const TeH::Ext r = teh_horner(partials, num_windows, chk, 0, cbits, planes, short_from);
   if (chk.bad) return true;
   teh_to_wire(r, out);
   return false;
@@ -625,17 +644,20 @@ inline void edh_to_wire(const EdH::Ext& p, uint8_t out[64]) {
   Fq64::to_wire(Fq64::mul(p.y, zi), out + 32);
 }
 // Same Horner as g1h_horner_bits; partials layout [window][point][32 words].  Bit positions [lo, hi) of the chain.
-inline EdH::Ext edh_horner_bits(const uint32_t* partials, int lo, int hi) {
+inline EdH::Ext edh_horner_bits(const uint32_t* partials, int lo, int hi, int short_from = 0) {
   EdH::Ext acc = EdH::identity();
   for (int b = hi - 1; b >= lo; b--) {
     acc = EdH::dbl(acc);
-    const int w = b >> 4, l = b & 15;
+    int w, l;
+    tail_position(b, 16, short_from, w, l);
     const uint32_t* base = partials + (size_t)w * 16 * 32;
     if (l < 15) acc = EdH::add(acc, edh_from_record_words(base + (size_t)(1 + l) * 32));
     if (l == 0) acc = EdH::add(acc, edh_from_record_words(base));
   }
   return acc;
 }
-inline void edh_combine(const uint32_t* partials, uint8_t out[64]) { edh_to_wire(edh_horner_bits(partials, 0, 256), out); }
+inline void edh_combine(const uint32_t* partials, uint8_t out[64], int short_from = 0) {
+  edh_to_wire(edh_horner_bits(partials, 0, tail_positions(16, 16, short_from), short_from), out);
+}
 
 }  // namespace msm377

@@ -79,14 +79,14 @@ inline bool single_threaded(const msm377_ctx* ctx) { return ctx->tail_threads <=
 
 }  // namespace
 
-int te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows, int cbits, int planes) {
-  if (single_threaded(ctx) || num_windows < 8) return teh_combine(partials, num_windows, out_xy, cbits, planes) ? TAIL_EXCEPTIONAL : TAIL_OK;
+int te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows, int cbits, int planes, int short_from) {
+  if (single_threaded(ctx) || num_windows < 8) return teh_combine(partials, num_windows, out_xy, cbits, planes, short_from) ? TAIL_EXCEPTIONAL : TAIL_OK;
   using St = TailState<TeH::Ext, TeFlags>;
   auto st = std::make_shared<St>();
   TeH::Ext r;
   const int rc = tail_horner_mt<TeH::Ext, TeFlags>(
-      ctx, [partials, cbits, planes](St& s, int lo, int hi, int k) { return teh_tail_piece(partials, lo, hi, s.extra.chk[k], cbits, planes); },
-      [](St& s, const TeH::Ext& a, const TeH::Ext& b, int k) { return s.extra.chk[k].add(a, b); }, cbits * num_windows, &r, st);
+      ctx, [partials, cbits, planes, short_from](St& s, int lo, int hi, int k) { return teh_tail_piece(partials, lo, hi, s.extra.chk[k], cbits, planes, short_from); },
+      [](St& s, const TeH::Ext& a, const TeH::Ext& b, int k) { return s.extra.chk[k].add(a, b); }, tail_positions(num_windows, cbits, short_from), &r, st);
   if (rc) return rc;
   for (const TeChecked& c : st->extra.chk)
     if (c.bad) return TAIL_EXCEPTIONAL;
@@ -94,42 +94,42 @@ int te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int n
   return TAIL_OK;
 }
 
-int xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]) {
+int xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int short_from) {
   if (single_threaded(ctx)) {
-    g1h_combine(partials, MSM377_NUM_WINDOWS, out_xy);
+    g1h_combine(partials, MSM377_NUM_WINDOWS, out_xy, short_from);
     return TAIL_OK;
   }
   using St = TailState<G1H::XYZZ, NoExtra>;
   G1H::XYZZ r;
   const int rc = tail_horner_mt<G1H::XYZZ, NoExtra>(
       ctx,
-      [partials](St&, int lo, int hi, int) {
-        G1H::XYZZ acc = g1h_horner_bits(partials, lo, hi);
+      [partials, short_from](St&, int lo, int hi, int) {
+        G1H::XYZZ acc = g1h_horner_bits(partials, lo, hi, 0, short_from);
         for (int i = 0; i < lo; i++) acc = G1H::dbl(acc);
         return acc;
       },
-      [](St&, const G1H::XYZZ& a, const G1H::XYZZ& b, int) { return G1H::add(a, b); }, 16 * MSM377_NUM_WINDOWS, &r, std::make_shared<St>());
+      [](St&, const G1H::XYZZ& a, const G1H::XYZZ& b, int) { return G1H::add(a, b); }, tail_positions(MSM377_NUM_WINDOWS, 16, short_from), &r, std::make_shared<St>());
   if (rc) return rc;
   g1h_to_wire(r, out_xy);
   return TAIL_OK;
 }
 
-int ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64]) {
+int ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64], int short_from) {
   if (single_threaded(ctx)) {
-    edh_combine(partials, out_xy);
+    edh_combine(partials, out_xy, short_from);
     return TAIL_OK;
   }
   using St = TailState<EdH::Ext, NoExtra>;
   EdH::Ext r;
   const int rc = tail_horner_mt<EdH::Ext, NoExtra>(
       ctx,
-      [partials](St&, int lo, int hi, int) {
-        EdH::Ext acc = edh_horner_bits(partials, lo, hi);
+      [partials, short_from](St&, int lo, int hi, int) {
+        EdH::Ext acc = edh_horner_bits(partials, lo, hi, short_from);
         for (int i = 0; i + 1 < lo; i++) acc = EdH::dbl_nt(acc);
         if (lo > 0) acc = EdH::dbl(acc);
         return acc;
       },
-      [](St&, const EdH::Ext& a, const EdH::Ext& b, int) { return EdH::add(a, b); }, 16 * MSM377_NUM_WINDOWS, &r, std::make_shared<St>());
+      [](St&, const EdH::Ext& a, const EdH::Ext& b, int) { return EdH::add(a, b); }, tail_positions(MSM377_NUM_WINDOWS, 16, short_from), &r, std::make_shared<St>());
   if (rc) return rc;
   edh_to_wire(r, out_xy);
   return TAIL_OK;

@@ -14,9 +14,9 @@ namespace eng {
 // GPU-side flag) or MSM377_EHIP (a helper thread did not answer within TailPool::wait_limit_ns; ctx->err says so).
 constexpr int TAIL_OK = 0, TAIL_EXCEPTIONAL = 1;
 
-int te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows = 16, int cbits = 16, int planes = 15);
-int xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96]);
-int ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64]);  // Edwards-BLS12: a complete law, nothing to check
+int te_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int num_windows = 16, int cbits = 16, int planes = 15, int short_from = 0);
+int xyzz_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[96], int short_from = 0);
+int ed_tail(msm377_ctx* ctx, const uint32_t* partials, uint8_t out_xy[64], int short_from = 0);  // Edwards-BLS12: a complete law, nothing to check
 
 // Inverses of the block products [b0, b1) the conversion's way up left in ctx->h_aff_prod, into ctx->h_aff_inv
 // (Montgomery's trick with one Fermat inversion per thread; results re-based to the device's Montgomery radix).

@@ -31,8 +31,18 @@ __device__ __forceinline__ uint32_t key_range(uint32_t key, uint32_t s) {
 // One thread per scalar: 16 signed digits d_w in [-2^15, 2^15), stored biased (d + 2^15).
 // Only windows [wb, wb + wc) are written (window sharding); the carry chain always runs over
 // all 16.  A final carry (scalar >= 2^255 - 2^239) sets *err, as cuzk/utils.ts:95-98 throws.
+//
+// even != 0 (whole MSMs, sequencer.hip Phase::even): the three bits a 253-bit scalar leaves unused are spread over the
+// top THREE windows instead of emptying the last one -- windows 0..12 as above, windows 13, 14, 15 take 15 bits each
+// (bit offsets 208, 223, 238: common.hpp even_offset) as UNSIGNED digits in [0, 2^15) with a carry chain of their own
+// (limb + carry = 2^15 -> digit 0, carry 1).  Every window then fills its 2^15 buckets with rows of n / 2^15 entries;
+// with sixteen 16-bit windows the top one holds 13 significant bits: n entries in 4096 rows, each cut into several
+// work items whose partial sums a merge kernel adds back (31 us at 2^20), and a sort with narrowed ranges for that
+// window (win_shift).  A scalar of 2^253 - 2^238 and more, whose top digit does not fit, raises ERR_NARROW_RANGE and
+// the call reruns with the sixteen equal windows; the ERROR condition stays the one of the 16-bit recode.
 __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n,
-                                                   uint32_t wb, uint32_t wc, int* __restrict__ err, uint32_t* __restrict__ top_key_max, uint32_t prio) {
+                                                   uint32_t wb, uint32_t wc, int* __restrict__ err, uint32_t* __restrict__ top_key_max, uint32_t prio,
+                                                   uint32_t even) {
   if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   // top_key_max (may be null): largest key of window 15, the one window that scalars below a 253-bit modulus leave
   // mostly empty; see win_shift.  One LDS atomic per thread at worst, one global atomic per block.
@@ -44,22 +54,45 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ 
     uint32_t w[8];
     load_words16(scalars + i * 8, w, 2);
     uint32_t carry = 0;
+    if (even) {
+      uint32_t carry16 = 0;  // the 16-bit recode's carry chain: the error condition
 #pragma unroll
-    for (uint32_t win = 0; win < 16; win++) {
-      uint32_t limb = (w[win >> 1] >> (16 * (win & 1))) & 0xffffu;
-      uint32_t v = limb + carry;
-      carry = v >= 32768u ? 1u : 0u;
-      if (win >= wb && win < wb + wc) {
-        const uint32_t biased = (v + 32768u) & 0xffffu;
-        digits[(size_t)(win - wb) * n + i] = (uint16_t)biased;
-        if (win == 15 && top_key_max) {
-          uint32_t key, sign;
-          digit_key(biased, key, sign);
-          if ((key | KEY_TRACKED) > wmax) atomicMax(&wmax, key | KEY_TRACKED);
+      for (uint32_t win = 0; win < 16; win++) {
+        const uint32_t limb = (w[win >> 1] >> (16 * (win & 1))) & 0xffffu;
+        carry16 = limb + carry16 >= 32768u ? 1u : 0u;
+        uint32_t biased;
+        if (win < EVEN_FROM) {
+          const uint32_t v = limb + carry;
+          carry = v >= 32768u ? 1u : 0u;
+          biased = (v + 32768u) & 0xffffu;
+        } else {
+          const uint32_t raw = win == 13 ? (w[6] >> 16) & 0x7fffu : win == 14 ? (w[6] >> 31) | ((w[7] & 0x3fffu) << 1) : (w[7] >> 14) & 0x7fffu;
+          const uint32_t v = raw + carry;
+          carry = v >> 15;
+          biased = (v & 0x7fffu) + 32768u;
+        }
+        if (win >= wb && win < wb + wc) digits[(size_t)(win - wb) * n + i] = (uint16_t)biased;
+      }
+      if (carry | (w[7] >> 29)) atomicOr(err, ERR_NARROW_RANGE);
+      if (carry16) atomicOr(err, ERR_SCALAR);
+    } else {
+#pragma unroll
+      for (uint32_t win = 0; win < 16; win++) {
+        uint32_t limb = (w[win >> 1] >> (16 * (win & 1))) & 0xffffu;
+        uint32_t v = limb + carry;
+        carry = v >= 32768u ? 1u : 0u;
+        if (win >= wb && win < wb + wc) {
+          const uint32_t biased = (v + 32768u) & 0xffffu;
+          digits[(size_t)(win - wb) * n + i] = (uint16_t)biased;
+          if (win == 15 && top_key_max) {
+            uint32_t key, sign;
+            digit_key(biased, key, sign);
+            if ((key | KEY_TRACKED) > wmax) atomicMax(&wmax, key | KEY_TRACKED);
+          }
         }
       }
+      if (carry) atomicOr(err, 1);
     }
-    if (carry) atomicOr(err, 1);
   }
   __syncthreads();
   if (threadIdx.x == 0 && top_key_max && wmax > *top_key_max) atomicMax(top_key_max, wmax);

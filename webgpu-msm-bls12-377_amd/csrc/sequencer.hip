@@ -249,6 +249,7 @@ struct Phase {
   // Wide windows over a precomputed table (kernels/wide.hpp): `table` holds [2^(20 w)] P_i for 13 windows, the call has
   // ONE window slot of 2^19 buckets fed by the flat list of 13 n digits (cbits = WIDE_BITS, bucket_log = WIDE_LOG).
   bool wide = false;
+  bool even = false;  // whole MSMs on 16 windows: the top three windows 15 bits wide (kernels/decompose.hpp k_decompose); the tail gets short_from = EVEN_FROM
   const uint32_t* bases_override = nullptr;  // base records of the call if not ctx->d_bases (the wide table's window 0 = the plain affine records)
   // Points that arrive in chunks (run_sorted_upload): ONE decomposition and sort of all scalars files every row's entries
   // by chunk (`cuts`), then each chunk's accumulation phase walks its own sub-rows (`chunk`) once its points are on the
@@ -301,7 +302,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // One memset clears this part's work-list counters AND its key_max words (0 = full-width ranges); k_decompose
   // then measures window 15 of the plain front end.
   hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, st, meta_block, META_BLOCK_WORDS, (uint32_t*)d_err, (ph.clear_err && part == 0) ? 1u : 0u);
-  uint32_t* top_key_max = (!glv && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
+  uint32_t* top_key_max = (!glv && !ph.even && pv.wb + wc == MSM377_NUM_WINDOWS) ? key_max + (wc - 1) : nullptr;
   const uint64_t max_items = (uint64_t)wc * NB + entries / SEG;  // every row has an item; extra ones are full segments
   // a lane quad per work item while the launch is one chain's latency (up to 2^14 points: ~94 k items); beyond that
   // the quads are VALU-bound like threads and only add their exchange instructions (kernel at 2^16: 0.216 / 0.183 ms)
@@ -320,7 +321,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     else if (glv)
       hipLaunchKernelGGL(k_decompose_glv, dim3((unsigned)((n_scalars + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n_scalars, pv.wb, wc, d_err);
     else
-      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err, top_key_max, wprio);
+      hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, pv.wb, wc, d_err, top_key_max, wprio, ph.even ? 1u : 0u);
     HIP_TRY(ctx, hipGetLastError());
   }
 
@@ -659,6 +660,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
     bool narrow = form != TABLE_TE_PRECOMP && n <= ctx->narrow_max_points && n <= SMALL_SORT_MAX && !ctx->capture;
     bool wide = form == TABLE_TE_PRECOMP && ctx->table_window_bits == WIDE_BITS;
     bool table0 = false;  // the 16-window path over window 0 of the wide table (= the affine records of the points themselves)
+    bool even = ctx->even_windows && form != TABLE_TE_PRECOMP && !ctx->capture;  // (stage read-backs describe sixteen equal windows)
     for (;;) {
       uint32_t windows = MSM377_NUM_WINDOWS;
       int cbits = MSM377_WINDOW_BITS, planes = MSM377_WINDOW_BITS - 1;
@@ -678,6 +680,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
         cbits = NARROW_BITS;
         planes = NARROW_LOG;
       }
+      ph.even = even && !wide && !narrow && !table0;
       ph.zc_out = true;
       int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, windows, 0, false, ph)
                                 : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, windows, 0, false, ph);
@@ -691,6 +694,10 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       }
       if (narrow && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar >= 2^253: the 16-bit path takes it
         narrow = false;
+        continue;
+      }
+      if (ph.even && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // likewise: sixteen equal windows take it
+        even = false;
         continue;
       }
       if (wide && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // likewise: its top window holds 19 bits
@@ -710,7 +717,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
       const int tr = form == TABLE_TE_PRECOMP && !table0 ? (teh_combine(ctx->h_partials, 1, out_xy, cbits, planes) ? TAIL_EXCEPTIONAL : TAIL_OK)
-                                              : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes);
+                                              : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes, ph.even ? (int)EVEN_FROM : 0);
       time_tail(ctx, t0);
       if (tr < 0) return tr;
       if (tr == TAIL_EXCEPTIONAL) note_fallback(ctx, MSM377_FB_TAIL);
@@ -768,6 +775,13 @@ int resident_table_to_weierstrass(msm377_ctx* ctx) {
 // before the first points are on the device; the per-chunk sorts the new schedule saves (~0.1 ms each) were hidden
 // behind the upload anyway, while its scalars-first head (0.78 ms of upload + 0.18 ms of sort before the first
 // accumulation) is not.
+// The chunks' decompositions use the even window geometry in the Edwards forms (g1_msm / ed_msm hand EVEN_FROM to the
+// tail and rerun in one piece when a scalar does not fit).
+template <class CV>
+inline bool upload_even(const msm377_ctx* ctx) {
+  return (std::is_same<CV, TeDev>::value || std::is_same<CV, EdDev>::value) && ctx->even_windows;
+}
+
 template <class CV>
 int run_chunked_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n) {
   constexpr size_t PB = CV::RAW_WORDS * 4;  // bytes per wire point
@@ -812,6 +826,7 @@ int run_chunked_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sc
     ph.into = c > 0;
     ph.back = c + 1 == K;
     ph.base_first = first;
+    ph.even = upload_even<CV>(ctx);
     rc = convert_bases<CV>(ctx, ctx->d_raw_points + first * CV::RAW_WORDS, cnt, first, c == 0);
     if (rc == MSM377_OK) rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars + first * 8, cnt, 0, MSM377_NUM_WINDOWS, 0, false, ph);
   }
@@ -875,6 +890,7 @@ int run_sorted_upload(msm377_ctx* ctx, const uint8_t* points, const uint8_t* sca
     ph.accumulate = false;
     ph.back = false;
     ph.cuts = cuts;
+    ph.even = upload_even<CV>(ctx);
     tr.gpu(ctx->stream, 0);
     rc = enqueue_windows<CV>(ctx, ctx->d_raw_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
     tr.gpu(ctx->stream, 1);
@@ -1005,11 +1021,19 @@ int g1_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
     if (rc) return rc;
     HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
     ctx->upload_trace.report();
-    if (!(te && (ctx->h_err[0] & ERR_TE_ANY))) {
+    const bool even = te && upload_even<TeDev>(ctx);
+    if (even && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & (ERR_SCALAR | ERR_TE_ANY))) {
+      // a scalar of 2^253 and more: everything is on the device by now, rerun in one piece (g1_table_msm falls back to
+      // sixteen equal windows by itself)
+      rc = convert_table(ctx, d_pt, n, form);
+      if (rc) return rc;
+      rc = g1_table_msm(ctx, d_sc, n, form, out_xy);
+      if (rc != RC_TE_FALLBACK) return rc;
+    } else if (!(te && (ctx->h_err[0] & ERR_TE_ANY))) {
       rc = finish_windows(ctx, 0);
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
-      const int tr = te ? te_tail(ctx, ctx->h_partials, out_xy) : xyzz_tail(ctx, ctx->h_partials, out_xy);
+      const int tr = te ? te_tail(ctx, ctx->h_partials, out_xy, 16, 16, 15, even ? (int)EVEN_FROM : 0) : xyzz_tail(ctx, ctx->h_partials, out_xy);
       time_tail(ctx, t0);
       if (tr != TAIL_EXCEPTIONAL) return tr;
       note_fallback(ctx, MSM377_FB_TAIL);
@@ -1059,17 +1083,32 @@ int ed_msm_device(msm377_ctx* ctx, const void* d_points, const void* d_scalars, 
   if (rc) return rc;
   TailArm arm(ctx);
   arm.at_start(n);
-  Phase ph;
-  ph.zc_out = true;
-  rc = enqueue_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
-  if (rc) return rc;
-  arm.after_accumulation();
-  rc = finish_windows(ctx, 0);
-  if (rc) return rc;
-  auto t0 = std::chrono::steady_clock::now();
-  rc = ed_tail(ctx, ctx->h_partials, out_xy);
-  time_tail(ctx, t0);
-  return rc;
+  bool even = ctx->even_windows && !ctx->capture && !ctx->ed_equal_windows_once;
+  ctx->ed_equal_windows_once = false;
+  for (;;) {
+    Phase ph;
+    ph.zc_out = true;
+    ph.even = even;
+    rc = enqueue_windows<EdDev>(ctx, (const uint32_t*)d_scalars, n, 0, MSM377_NUM_WINDOWS, 0, false, ph);
+    if (rc) return rc;
+    arm.after_accumulation();
+    if (ctx->zc_active) {
+      rc = wait_zero_copy_out(ctx);
+      if (rc) return rc;
+    } else {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    }
+    if (even && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar of 2^253 and more: sixteen equal windows
+      even = false;
+      continue;
+    }
+    rc = finish_windows(ctx, 0);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = ed_tail(ctx, ctx->h_partials, out_xy, even ? (int)EVEN_FROM : 0);
+    time_tail(ctx, t0);
+    return rc;
+  }
 }
 
 int ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint64_t n, uint8_t out_xy[64]) {
@@ -1085,10 +1124,16 @@ int ed_msm(msm377_ctx* ctx, const uint8_t* points, const uint8_t* scalars, uint6
     ctx->bases_n = 0;
     int rc = ctx->upload_sort_once ? run_sorted_upload<EdDev>(ctx, points, scalars, n) : run_chunked_upload<EdDev>(ctx, points, scalars, n);
     if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
+    const bool even = upload_even<EdDev>(ctx);
+    if (even && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // everything is on the device: once more in one piece
+      ctx->ed_equal_windows_once = true;
+      return ed_msm_device(ctx, ctx->d_raw_points, ctx->d_raw_scalars, n, out_xy);
+    }
     rc = finish_windows(ctx, 0);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    rc = ed_tail(ctx, ctx->h_partials, out_xy);
+    rc = ed_tail(ctx, ctx->h_partials, out_xy, even ? (int)EVEN_FROM : 0);
     time_tail(ctx, t0);
     return rc;
   }
@@ -1251,17 +1296,19 @@ static int fixed_base_batch_share(msm377_ctx* ctx, const void* d_scalars, uint64
     table_phase.cbits = WIDE_BITS;
     table_phase.bucket_log = WIDE_LOG;
   }
-  const int tail_cbits = wide ? (int)WIDE_BITS : 16, tail_planes = wide ? (int)WIDE_LOG : 15;
+  const bool even = te && form != TABLE_TE_PRECOMP && ctx->even_windows;  // (the Weierstrass forms keep sixteen equal windows)
+  table_phase.even = even;
+  const int tail_cbits = wide ? (int)WIDE_BITS : 16, tail_planes = wide ? (int)WIDE_LOG : 15, tail_short = even ? (int)EVEN_FROM : 0;
   const int W_tail = form == TABLE_TE_PRECOMP ? 1 : (int)W;  // window records the host combines per MSM
   std::vector<uint32_t> redo;  // elements whose scalars fall outside the GLV range: rerun plain afterwards
-  std::vector<uint32_t> redo_wide;  // elements with a scalar of 2^253 and more on the wide table: rerun one by one (g1_table_msm falls back)
+  std::vector<uint32_t> redo_wide;  // elements with a scalar of 2^253 and more on the wide table or the even windows: rerun one by one (g1_table_msm falls back)
   bool te_fallback = false;
   // Software pipeline over the batch: while the GPU runs MSM b, the host finishes MSM b-1
   // (Horner + inversion on the other slot's partial records).
   for (uint32_t b = 0; b <= batch; b++) {
     if (b < batch && !te_fallback) {
       rc = (form == TABLE_TE_AFFINE || form == TABLE_TE_PRECOMP) ? enqueue_windows<TeDev, TeAffBase>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), false, table_phase)
-           : te                    ? enqueue_windows<TeDev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1))
+           : te                    ? enqueue_windows<TeDev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), false, table_phase)
                                    : enqueue_windows<G1Dev>(ctx, sc + (size_t)b * n * 8, n, 0, W, (int)(b & 1), glv);
       if (rc) return rc;
     }
@@ -1277,7 +1324,7 @@ static int fixed_base_batch_share(msm377_ctx* ctx, const void* d_scalars, uint64
         redo.push_back(b - 1);
         continue;
       }
-      if (wide && (ctx->h_err[slot] & ERR_NARROW_RANGE) && !(ctx->h_err[slot] & ERR_SCALAR)) {
+      if ((wide || even) && (ctx->h_err[slot] & ERR_NARROW_RANGE) && !(ctx->h_err[slot] & ERR_SCALAR)) {
         redo_wide.push_back(b - 1);
         continue;
       }
@@ -1287,7 +1334,7 @@ static int fixed_base_batch_share(msm377_ctx* ctx, const void* d_scalars, uint64
         return rc;
       }
       if (te) {
-        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W_tail, out_xy + (size_t)96 * (b - 1), tail_cbits, tail_planes)) {
+        if (teh_combine(ctx->h_partials + (size_t)slot * SLOT_WORDS, W_tail, out_xy + (size_t)96 * (b - 1), tail_cbits, tail_planes, tail_short)) {
           te_fallback = true;
           note_fallback(ctx, MSM377_FB_TAIL);
         }
@@ -1304,7 +1351,7 @@ static int fixed_base_batch_share(msm377_ctx* ctx, const void* d_scalars, uint64
     if (rc) return rc;
   }
   for (uint32_t b : redo_wide) {
-    rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, TABLE_TE_PRECOMP, out_xy + (size_t)96 * b);
+    rc = g1_table_msm(ctx, sc + (size_t)b * n * 8, n, form, out_xy + (size_t)96 * b);
     if (rc) return rc;  // RC_TE_FALLBACK included
   }
   return MSM377_OK;
