@@ -94,11 +94,13 @@ int msm377_g1_set_bases_device(msm377_ctx* ctx, const void* d_points, uint64_t n
  * GPU: ONE bucket reduction, one partial record and a 16-step host tail per MSM instead of 16 and 256.  Results are
  * identical.  In the Weierstrass form (msm377_ctx_set_g1_form 0) this is msm377_g1_set_bases. */
 /* Window width of the tables the next msm377_g1_set_bases_precomputed* call builds: MSM377_WINDOW_BITS (16, default: the
- * layout above) or MSM377_WIDE_WINDOW_BITS (20): [2^(20 w)] P_i for 13 windows (13 n affine records, 2.2 GB at n = 2^20).
+ * layout above) or MSM377_WIDE_WINDOW_BITS (20): 13 windows -- six of 20 bits, then seven of 19, 253 bits in all -- with
+ * [2^(offset of window w)] P_i in the table (13 n affine records, 2.2 GB at n = 2^20).
  * Because every window's points already carry its weight, all windows share ONE bucket set, so the window can widen
  * without multiplying buckets: 13 n bucket additions per MSM instead of 16 n over 2^19 buckets -- as many as the
  * 16 x 2^15 of the plain path -- one 19-level reduction, a 20-step host tail.  (21-bit windows are still 13 for a
- * 253-bit scalar; 22-bit ones quadruple the buckets.)  Results are identical. */
+ * 253-bit scalar; 22-bit ones quadruple the buckets.)  A scalar of 2^253 and more (none below the group order) reruns
+ * on the 16-window path over the table's first window.  Results are identical. */
 #define MSM377_WIDE_WINDOW_BITS 20
 int msm377_ctx_set_precompute_window(msm377_ctx* ctx, int window_bits);
 int msm377_g1_set_bases_precomputed(msm377_ctx* ctx, const uint8_t* points, uint64_t n);
@@ -107,7 +109,11 @@ int msm377_g1_set_bases_precomputed_device(msm377_ctx* ctx, const void* d_points
 int msm377_g1_msm_fixed_base(msm377_ctx* ctx, const uint8_t* scalars, uint64_t n, uint8_t out_xy[96]);
 int msm377_g1_msm_fixed_base_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint8_t out_xy[96]);
 /* `batch` MSMs over the resident bases in one call: d_scalars holds batch x n x 32 bytes, out_xy
- * receives batch x 96 bytes.  The host tail of MSM b overlaps the GPU work of MSM b+1. */
+ * receives batch x 96 bytes.  The host tail of MSM b overlaps the GPU work of MSM b+1.  From batch = 4 on the call runs
+ * as two halves side by side on two sets of streams and work buffers (a "twin" of the context's buffers, created with
+ * the first such call: the context's device memory without the tables, ~0.7 GB at 2^20 points, a second time; if that
+ * allocation fails, or with MSM377_TWIN_BATCH=0, the batch runs on one set) -- the low-occupancy ends of one MSM fill
+ * with the other half's kernels: 2.16 -> 2.05 ms per MSM at 2^20, 2.00 -> 1.89 on the 20-bit-window table. */
 int msm377_g1_msm_fixed_base_batch_device(msm377_ctx* ctx, const void* d_scalars, uint64_t n, uint32_t batch, uint8_t* out_xy);
 
 /* Window sharding for multi-GPU runs (the reference already treats the

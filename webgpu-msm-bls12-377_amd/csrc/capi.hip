@@ -89,8 +89,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   // path: main stream high 2.554 ms, side stream high 2.583, equal 2.603 at 2^20 -- profiles/r03_final/ab_prio_prewake.txt.)
   ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->acc_done, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) == hipSuccess;
   auto dalloc = [&](void** p, size_t bytes) { ok = ok && hipMalloc(p, bytes) == hipSuccess; };
   dalloc((void**)&ctx->d_raw_points, cap * 96);
   dalloc((void**)&ctx->d_raw_scalars, cap * 32);
@@ -125,8 +124,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
        hipHostGetDevicePointer((void**)&ctx->dm_aff_prod, ctx->h_aff_prod, 0) == hipSuccess &&
        hipHostGetDevicePointer((void**)&ctx->dm_aff_inv, ctx->h_aff_inv, 0) == hipSuccess &&
        hipHostGetDevicePointer((void**)&ctx->dm_aff_flag, ctx->h_aff_flag, 0) == hipSuccess &&
-       hipEventCreateWithFlags(&ctx->aff_up_done, hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&ctx->sort_done, hipEventDisableTiming) == hipSuccess;
+       hipEventCreateWithFlags(&ctx->aff_up_done, hipEventDisableTiming) == hipSuccess;
   if (ok) ctx->aff_scratch.resize(aff_blocks);
   dalloc((void**)&ctx->d_err, 4 * sizeof(int));  // [0], [1]: the two pipeline slots; [2]: base conversion (lives with the table)
   ok = ok && hipHostMalloc((void**)&ctx->h_partials, (size_t)2 * SLOT_WORDS * 4, host_flags) == hipSuccess &&
@@ -171,7 +169,6 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
   if (ctx->h_aff_inv) (void)hipHostFree(ctx->h_aff_inv);
   if (ctx->h_aff_flag) (void)hipHostFree(ctx->h_aff_flag);
   if (ctx->aff_up_done) (void)hipEventDestroy(ctx->aff_up_done);
-  if (ctx->sort_done) (void)hipEventDestroy(ctx->sort_done);
   for (int t = 0; t < 8; t++)
     if (ctx->copy_stream[t]) (void)hipStreamDestroy(ctx->copy_stream[t]);
   for (int k = 0; k < 2; k++)
@@ -181,7 +178,6 @@ void msm377_ctx_destroy(msm377_ctx* ctx) {
       for (int p = 0; p < 2; p++)
         if (ctx->ev[p][s][k]) (void)hipEventDestroy(ctx->ev[p][s][k]);
   if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
-  if (ctx->acc_done) (void)hipEventDestroy(ctx->acc_done);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

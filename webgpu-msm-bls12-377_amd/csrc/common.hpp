@@ -74,6 +74,7 @@ inline uint32_t affine_blocks(uint64_t n) { return (uint32_t)((n + AFF_BLOCK_POI
 
 // ---- wide windows over a precomputed table (kernels/wide.hpp) ----
 // Whole MSMs on the 16-window path: windows 13, 14, 15 are 15 bits wide (kernels/decompose.hpp k_decompose, `even`).
+constexpr uint32_t ACC_FLAG_WORD = 4;  // word of the pinned flag line (ctx->h_out_flag) that says "the accumulation kernel of call #seq is through"
 constexpr uint32_t EVEN_FROM = 13;
 constexpr uint32_t even_offset(uint32_t w) { return 16 * w - (w > EVEN_FROM ? w - EVEN_FROM : 0u); }
 static_assert(even_offset(13) == 208 && even_offset(14) == 223 && even_offset(15) == 238 && even_offset(16) == 253, "13 x 16 + 3 x 15 = 253 bits");

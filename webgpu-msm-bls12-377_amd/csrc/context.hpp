@@ -110,7 +110,6 @@ struct msm377_ctx {
   uint32_t *dm_aff_prod = nullptr, *dm_aff_inv = nullptr, *dm_aff_flag = nullptr;
   uint32_t* d_aff_count = nullptr;    // workgroups of k_affine_up that have delivered (device memory; the last one resets it)
   hipEvent_t aff_up_done = nullptr;
-  hipEvent_t sort_done = nullptr;     // recorded behind k_local_sort of the current call (main stream)
   uint32_t table_window_bits = MSM377_WINDOW_BITS;  // window width of the resident precomputed table: 16, or WIDE_BITS (six 20-bit + seven 19-bit windows)
   uint32_t table_doublings = MSM377_WINDOW_BITS;    // doublings from the previous window's multiple to the one being built (AffDoublingSource)
   std::vector<Fp64::El> aff_scratch;  // prefix products of the host's share of Montgomery's trick
@@ -167,7 +166,6 @@ struct msm377_ctx {
   bool last_glv = false;
   uint32_t seg_plain = 0, seg_glv = 0;  // MSM377_SEG_PLAIN / MSM377_SEG_GLV: force the work-item length (SEG_MIN..SEG_MAX), 0 = auto_seg()
   hipEvent_t ev[2][MSM377_NUM_STAGES][2] = {};  // [part][stage][begin, end]
-  hipEvent_t acc_done = nullptr;      // recorded behind the accumulation kernel (TailArm: the host arms the tail workers then)
   uint64_t upload_chunk_min = 1ull << 18;  // msm377_g1_msm: inputs of at least this many points upload and run as two chunks (MSM377_UPLOAD_CHUNK_MIN)
   UploadTrace upload_trace;
   bool upload_trace_on = false;           // MSM377_UPLOAD_TRACE=1
@@ -201,6 +199,7 @@ struct msm377_ctx {
   // Batches on two sets of streams and buffers (sequencer.hip twin_prepare)
   bool even_windows = true;     // MSM377_EVEN_WINDOWS=0: sixteen 16-bit windows on every path (kernels/decompose.hpp k_decompose)
   bool ed_equal_windows_once = false;  // ed_msm -> ed_msm_device: this call reruns a chunked upload whose scalars did not fit
+  uint32_t acc_seq = 0;  // calls' accumulation kernels so far; h_out_flag[ACC_FLAG_WORD] follows it (k_merge_split_rows_quad)
   msm377_ctx* twin = nullptr;   // owned; borrows d_bases / d_table for the length of a batch call
   bool twin_batches = true;     // MSM377_TWIN_BATCH=0: batches run on this context alone
   bool twin_failed = false;

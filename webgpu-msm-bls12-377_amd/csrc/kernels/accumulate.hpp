@@ -89,30 +89,28 @@ __global__ void __launch_bounds__(1024) k_work_hist(const uint32_t* __restrict__
   }
 }
 
-// One block (SEG_BINS <= 256): cursor[b] = number of items longer than b (descending order), total item count.
-__global__ void __launch_bounds__(256) k_work_scan(const uint32_t* __restrict__ work_hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ total, uint32_t prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
-  __shared__ uint32_t h[SEG_BINS];
-  const uint32_t tid = threadIdx.x;
-  if (tid < SEG_BINS) h[tid] = work_hist[tid];
-  __syncthreads();
-  if (tid < SEG_BINS) {
-    uint32_t c = 0;
-    for (uint32_t b = tid + 1; b < SEG_BINS; b++) c += h[b];
-    cursor[tid] = c;
-    if (tid == 0) *total = c + h[0];
-  }
-}
-
-// Thread per row again: claims its slots in the sorted work list.
-__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG, uint32_t* __restrict__ cursor,
+// Thread per row again: claims its slots in the work list, which is sorted by item length, longest first: the items of
+// length b start behind all longer ones, at first[b] = sum of work_hist[b' > b] -- every workgroup works that out for
+// itself from the finished histogram (129 words; a launch of its own for this scan cost 5 us of every call) -- and
+// cursor[b] (zero at the start: the meta block's clear) counts the slots of that length handed out so far.
+__global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restrict__ row_ptr, uint32_t L, uint32_t rows, uint32_t SEG,
+                                                      const uint32_t* __restrict__ work_hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ total,
                                                       WorkItem* __restrict__ work, RowView rv, uint32_t prio) {
   if (prio) __builtin_amdgcn_s_setprio(3);  // sequencer.hip: front-end kernels outrank the conversion beside them
   __shared__ uint32_t lh[SEG_BINS];
   __shared__ uint32_t lbase[SEG_BINS];
+  __shared__ uint32_t gh[SEG_BINS];
   const uint32_t tid = threadIdx.x, row = blockIdx.x * 1024 + tid;
-  if (tid < SEG_BINS) lh[tid] = 0;
+  if (tid < SEG_BINS) {
+    lh[tid] = 0;
+    gh[tid] = work_hist[tid];
+  }
   __syncthreads();
+  uint32_t first = 0;  // of this thread's bin
+  if (tid < SEG_BINS) {
+    for (uint32_t b = tid + 1; b < SEG_BINS; b++) first += gh[b];
+    if (tid == 0 && blockIdx.x == 0) *total = first + gh[0];  // the item count k_accumulate reads
+  }
   RowSplit sp = {0, 0, 0};
   uint32_t rank_full = 0, rank_last = 0;
   if (row < rows) {
@@ -121,7 +119,7 @@ __global__ void __launch_bounds__(1024) k_work_scatter(const uint32_t* __restric
     rank_last = atomicAdd(&lh[sp.lastlen], 1u);
   }
   __syncthreads();
-  if (tid < SEG_BINS && lh[tid]) lbase[tid] = atomicAdd(&cursor[tid], lh[tid]);
+  if (tid < SEG_BINS && lh[tid]) lbase[tid] = first + atomicAdd(&cursor[tid], lh[tid]);
   __syncthreads();
   if (row < rows) {
     for (uint32_t s = 0; s + 1 < sp.nseg; s++) work[lbase[sp.seglen] + rank_full + s] = WorkItem{row, s};
@@ -300,7 +298,11 @@ template <class CV>
 __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t* __restrict__ row_ptr, uint32_t* __restrict__ buckets,
                                                                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ split_rows,
                                                                   const uint32_t* __restrict__ row_ovf_base, const uint32_t* __restrict__ ovf, uint32_t SEG,
-                                                                  int* __restrict__ err, uint32_t L, RowView rv) {
+                                                                  int* __restrict__ err, uint32_t L, RowView rv, uint32_t* __restrict__ host_flag, uint32_t seq) {
+  // The first launch behind the accumulation kernel tells the host that it is through (sequencer.hip TailArm: the
+  // tail's helper threads start polling for their jobs now).  An event record between the two kernels did the same and
+  // cost a ~6 us bubble in the stream.
+  if (host_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t count = counters[0];
   const uint32_t q = threadIdx.x & 3;
   for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < count; i += gridDim.x * 64) {

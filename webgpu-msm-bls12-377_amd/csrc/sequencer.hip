@@ -337,12 +337,10 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(WIDE_NRANGE, 1), dim3(256), 0, st, (const SortElem*)ctx->d_wide_temp, region_base, row_ptr, val_idx, entries,
                        (const uint32_t*)nullptr, WIDE_NRANGE, NB, ChunkCuts{}, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   } else if (narrow) {
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
     hipLaunchKernelGGL(k_small_sort, dim3(wc), dim3(1024), 0, st, digits, row_ptr, val_idx, (uint32_t)n, L);
     HIP_TRY(ctx, hipGetLastError());
-    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   } else {
     StageTimer t(ctx, MSM377_STAGE_SORT, st, part);
     uint32_t chunks = sort_blocks / wc;
@@ -360,7 +358,6 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     else
       hipLaunchKernelGGL(k_local_sort_lds<false>, dim3(NRANGE, wc), dim3(256), 0, st, sort_temp, region_base, row_ptr, val_idx, n, key_max, NRANGE, NB, ChunkCuts{}, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->sort_done, st));
   }
   }  // ph.sort
   if (ph.accumulate) {
@@ -373,9 +370,7 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     uint32_t* counters = meta + 2 * SEG_BINS + 1;  // [0] split rows, [1] overflow slots
     hipLaunchKernelGGL(k_work_hist, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, work_hist, row_ovf_base, counters, split_rows, rv, wprio);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scan, dim3(1), dim3(256), 0, st, work_hist, cursor, total, wprio);
-    HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, cursor, work, rv, wprio);
+    hipLaunchKernelGGL(k_work_scatter, dim3((rows + 1023) / 1024), dim3(1024), 0, st, row_ptr, L, rows, SEG, (const uint32_t*)work_hist, cursor, total, work, rv, wprio);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->before_accumulate) {  // must run before the wait below is queued: the wait binds to the event's latest record
       std::function<int()> f;
@@ -405,9 +400,10 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
                            ctx->d_err + 2, ph.into ? 1u : 0u, ph.table_stride, L, rv);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (part == 0) HIP_TRY(ctx, hipEventRecord(ctx->acc_done, st));
+    if (part == 0) ctx->acc_seq++;
     static_assert(CV::HAS_QUAD, "every curve policy has the quad-cooperative addition");
-    hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3((rows + 63) / 64), dim3(256), 0, st, row_ptr, buckets, counters, split_rows, row_ovf_base, ovf, SEG, d_err, L, rv);
+    hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3((rows + 63) / 64), dim3(256), 0, st, row_ptr, buckets, counters, split_rows, row_ovf_base, ovf, SEG, d_err, L, rv,
+                       part == 0 ? ctx->dm_out_flag + ACC_FLAG_WORD : (uint32_t*)nullptr, ctx->acc_seq);
     HIP_TRY(ctx, hipGetLastError());
   }  // ph.accumulate
   }  // ph.front
@@ -640,7 +636,13 @@ struct TailArm {
   }
   void after_accumulation() {
     if (armed || c->tail_threads <= 1 || c->tail_spin_us <= 0) return;
-    if (hipEventSynchronize(c->acc_done) != hipSuccess) return;  // the caller's own wait reports the error
+    // k_merge_split_rows_quad, the launch behind the accumulation kernel, writes the call's sequence number; without it
+    // within 100 ms the caller's own wait reports whatever went wrong
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; __atomic_load_n(&c->h_out_flag[ACC_FLAG_WORD], __ATOMIC_ACQUIRE) != c->acc_seq; spins++) {
+      __builtin_ia32_pause();
+      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) return;
+    }
     arm();
   }
   ~TailArm() { c->tail_pool.disarm(); }
