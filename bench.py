@@ -492,7 +492,7 @@ def main():
             "dtype": "u32 (29-bit limbs, 64-bit accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": "2^%d BLS12-377 G1 (short Weierstrass) MSM, 16-bit signed windows, inputs resident in HBM" % args.log_n,
+                "workload": "2^%d BLS12-377 G1 (short Weierstrass) MSM, 16-bit signed windows (the top three: 15 bits, unsigned), inputs resident in HBM" % args.log_n,
                 "front_end": "GLV: 8 windows over the 2n points {P_i, phi(P_i)}" if glv_path else "plain: 16 windows over n points",
                 "coordinates": "twisted Edwards form of G1, extended coordinates (csrc/te377.hpp)" if te_path else "short Weierstrass, XYZZ",
                 "points": "P_i=[a_i]G, a_i=SplitMix64(0x377)",

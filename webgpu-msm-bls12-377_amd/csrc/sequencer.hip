@@ -402,7 +402,9 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     HIP_TRY(ctx, hipGetLastError());
     if (part == 0) ctx->acc_seq++;
     static_assert(CV::HAS_QUAD, "every curve policy has the quad-cooperative addition");
-    hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3((rows + 63) / 64), dim3(256), 0, st, row_ptr, buckets, counters, split_rows, row_ovf_base, ovf, SEG, d_err, L, rv,
+    // (grid-stride over the split-row list: with the even windows few rows split, and 8192 workgroups that only read the
+    // count cost 11 us at 2^20)
+    hipLaunchKernelGGL(k_merge_split_rows_quad<CV>, dim3(std::min<uint32_t>((rows + 63) / 64, 1024u)), dim3(256), 0, st, row_ptr, buckets, counters, split_rows, row_ovf_base, ovf, SEG, d_err, L, rv,
                        part == 0 ? ctx->dm_out_flag + ACC_FLAG_WORD : (uint32_t*)nullptr, ctx->acc_seq);
     HIP_TRY(ctx, hipGetLastError());
   }  // ph.accumulate
