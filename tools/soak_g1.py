@@ -1,4 +1,5 @@
-"""Randomized parity soak (not part of the test suite): sizes 1..100003, uniform / short / skewed / near-r scalars,
+"""Randomized parity soak (not part of the test suite): sizes 1..100003, uniform / short / skewed / near-r scalars and
+scalars of 2^253 and more (the even and wide window geometries rerun those), batches of 5 (the twin context),
 all three internal paths, host (chunked upload forced from 3000 points, both schedules), device, fixed-base and
 precomputed-table (16- and 20-bit windows) entry points, against
 the CPU oracle.  Runs for ~150 s; exit code 1 on any mismatch."""
@@ -22,7 +23,7 @@ while time.time() - t0 < 150:
     r2 = random.Random(seed)
     pts = util.oracle_gen_points(oracle, n, r2.randrange(1, 1 << 200), r2.randrange(1, 1 << 200))
     ks = R.encode_scalars(R.rand_scalars(seed, n))
-    mode = rnd.choice(["uniform", "small", "skew", "top"])
+    mode = rnd.choice(["uniform", "small", "skew", "top", "big"])
     if mode == "small":
         ks = R.encode_scalars([rnd.randrange(1 << rnd.choice([1, 16, 17, 64, 128])) for _ in range(n)])
     elif mode == "skew":
@@ -30,6 +31,11 @@ while time.time() - t0 < 150:
         ks = R.encode_scalars([rnd.choice(hot) if rnd.random() < 0.9 else rnd.randrange(R.R_ORDER) for _ in range(n)])
     elif mode == "top":
         ks = R.encode_scalars([R.R_ORDER - 1 - rnd.randrange(1 << 20) for _ in range(n)])
+    elif mode == "big":  # a few scalars the short top windows cannot hold, below the error threshold 2^255 - 2^239
+        kl = R.decode_scalars(ks)
+        for _ in range(rnd.randrange(1, 4)):
+            kl[rnd.randrange(n)] = rnd.choice([(1 << 253) + rnd.randrange(1 << 200), (0x7FFF << 238) + (0x7FFF << 223) + (0x7FFF << 208) + (1 << 207), (1 << 254) + rnd.randrange(1 << 250)])
+        ks = R.encode_scalars(kl)
     exp = util.oracle_msm(oracle, pts, ks)
     for form, glv in (("edwards", "auto"), ("weierstrass", False), ("weierstrass", True)):
         eng.set_g1_form(form); eng.set_glv(glv)
@@ -49,6 +55,12 @@ while time.time() - t0 < 150:
         eng.set_bases_precomputed(pts)
         if eng.msm_fixed_base(ks) != exp:
             bad += 1; print("MISMATCH precomputed", bits, n, seed, mode, flush=True)
+        if n >= 64:  # a batch of 5 over the table: two halves on the twin context
+            ks2 = R.encode_scalars(R.rand_scalars(seed + 1, n))
+            d_b = torch.frombuffer(bytearray(ks + ks2 + ks + ks2 + ks), dtype=torch.uint8).cuda()
+            exp2 = util.oracle_msm(oracle, pts, ks2)
+            if eng.msm_fixed_base_batch_device(d_b.data_ptr(), n, 5) != [exp, exp2, exp, exp2, exp]:
+                bad += 1; print("MISMATCH precomputed batch", bits, n, seed, mode, flush=True)
     eng.set_precompute_window(16)
     if eng_once.msm(pts, ks) != exp:  # host buffers, sorted once (MSM377_UPLOAD_SORT_ONCE=1), 7 chunks
         bad += 1; print("MISMATCH sort-once upload", n, seed, mode, flush=True)
