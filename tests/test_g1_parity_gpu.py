@@ -671,6 +671,20 @@ def test_fixed_base_batch_pipeline(engine, oracle, path):
         engine.msm_fixed_base_batch_device(d_bad.data_ptr(), n, batch)
     assert e.value.code == -3
     assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 2) == got[:2]
+    # ... also in the half of the batch that runs on the twin context (elements 3 and 4 of 5), whose error and message
+    # the call hands on; and an element there that has to rerun alone
+    bad = bytearray(b"".join(sets))
+    bad[32 * (4 * n + 7) : 32 * (4 * n + 8)] = b"\xff" * 32
+    d_bad = dev(bytes(bad))
+    with pytest.raises(msm.MsmError) as e:
+        engine.msm_fixed_base_batch_device(d_bad.data_ptr(), n, batch)
+    assert e.value.code == -3 and "scalar" in str(e.value)
+    assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, batch) == got
+    late = list(sets)
+    late[4] = R.encode_scalars(ks_int)
+    d_l = dev(b"".join(late))
+    got_l = engine.msm_fixed_base_batch_device(d_l.data_ptr(), n, batch)
+    assert got_l[:4] == got[:4] and got_l[4] == got_m[2]
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 8, 3])
