@@ -197,6 +197,7 @@ struct msm377_ctx {
   // round 2: 2^16 0.605 / 0.56 (its bucket reduction 0.28 / 0.10 ms, its accumulation kernel 0.14 / 0.18), hence 2^16.
   uint64_t narrow_max_points = 1ull << 16;
   // Batches on two sets of streams and buffers (sequencer.hip twin_prepare)
+  bool tail_lds = true;         // MSM377_TAIL_LDS=0: the single-launch reduction tail works in global memory (k_reduce_tail)
   bool even_windows = true;     // MSM377_EVEN_WINDOWS=0: sixteen 16-bit windows on every path (kernels/decompose.hpp k_decompose)
   bool ed_equal_windows_once = false;  // ed_msm -> ed_msm_device: this call reruns a chunked upload whose scalars did not fit
   uint32_t acc_seq = 0;  // calls' accumulation kernels so far; h_out_flag[ACC_FLAG_WORD] follows it (k_merge_split_rows_quad)

@@ -254,6 +254,71 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __res
   if (bad) atomicOr(err, ERR_TE_TREE);
 }
 
+// The same with the workgroup's stretch of the bucket array in LDS.  At level `first` every list -- and the running
+// block -- is R = NB >> first buckets long and everything a workgroup touches from there on lies inside its R buckets
+// (a list only shrinks; the lists the running block spawns are its own upper halves), so the workgroup reads them once
+// (R x 208 bytes, 52 KB for R = 256: records packed to their 52 words, which also spreads 16 quads' reads over the
+// banks), runs all remaining levels out of LDS -- a level is then one quad addition plus a barrier instead of that plus
+// an L2 round trip for loads and stores -- and writes back only the heads the gather kernel reads (B[0] and B[2^l]).
+template <class CV>
+__device__ __forceinline__ typename CV::Pt lds_point(const uint32_t* p) {
+  uint32_t w[CV::PT_WORDS];
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (uint32_t k = 0; k < CV::PT_WORDS / 4; k++) {
+    const uint4 v = s[k];
+    w[4 * k + 0] = v.x;
+    w[4 * k + 1] = v.y;
+    w[4 * k + 2] = v.z;
+    w[4 * k + 3] = v.w;
+  }
+  return CV::from_words(w);
+}
+constexpr uint32_t TAIL_LDS_BYTES_MAX = 160 * 1024;  // a workgroup may take all of a CU's LDS on gfx950 (beyond 64 KB: hipFuncSetAttribute, sequencer.hip)
+template <class CV>
+__global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail_lds(uint32_t* __restrict__ buckets, uint32_t L, uint32_t first, int* __restrict__ err) {
+  extern __shared__ uint4 tail_lds4[];
+  uint32_t* lds = reinterpret_cast<uint32_t*>(tail_lds4);
+  constexpr uint32_t PW = CV::PT_WORDS, NL = CV::NL;
+  static_assert(PW % 4 == 0 && PW == 4 * NL, "a packed record is four coordinates of NL limbs, a multiple of 16 bytes");
+  const uint32_t NB = 1u << L, R = NB >> first;
+  const uint32_t ws = blockIdx.y, job = blockIdx.x;  // job < first: list `job`; job == first: the running block
+  const uint32_t q = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  const uint32_t base = job < first ? (NB >> (job + 1)) : 0u;  // first bucket of this workgroup's stretch
+  for (uint32_t i = threadIdx.x; i < R * 4; i += TAIL_THREADS) {  // (bucket, coordinate)
+    const uint32_t* src = bucket_ptr<CV>(buckets, L, ws, base + (i >> 2)) + (i & 3) * CV::COORD_WORDS;
+    uint32_t* dst = lds + (size_t)i * NL;
+#pragma unroll
+    for (uint32_t j = 0; j < NL; j++) dst[j] = src[j];
+  }
+  __syncthreads();
+  bool bad = false;
+  for (uint32_t r = first; r < L; r++) {
+    const uint32_t half = NB >> (r + 1);
+    const uint32_t nlists = job < first ? 1u : 1u + (r - first);
+    for (uint32_t op = quad; op < nlists * half; op += TAIL_THREADS / 4) {
+      const uint32_t li = op / half, kk = op % half;
+      const uint32_t lo = (job < first || li == 0) ? 0u : (NB >> (first + li));  // inside the stretch
+      const uint32_t x = lo + kk, y = x + half;
+      const typename CV::Pt sum = add_quad(lds_point<CV>(lds + (size_t)x * PW), lds_point<CV>(lds + (size_t)y * PW), q);
+      bad |= CV::is_bad(sum);
+      const typename CV::F::El c = coord4(q, sum);
+      uint32_t* d = lds + (size_t)x * PW + q * NL;  // the quad's four lanes have read x before any of them writes (one wave, in order)
+#pragma unroll
+      for (uint32_t j = 0; j < NL; j++) d[j] = c.l[j];
+    }
+    __syncthreads();
+  }
+  if (bad) atomicOr(err, ERR_TE_TREE);
+  // heads: bucket 0 of the stretch, and for the running block the lists it spawned, at 2^k for k < L - first
+  const uint32_t heads = job < first ? 1u : 1u + (L - first);
+  if (threadIdx.x < heads * 4) {
+    const uint32_t h = threadIdx.x >> 2, c = threadIdx.x & 3;
+    const uint32_t idx = h == 0 ? 0u : (1u << (h - 1));
+    store_coord<CV>(bucket_ptr<CV>(buckets, L, ws, base + idx) + c * CV::COORD_WORDS, lds + (size_t)idx * PW + c * NL);
+  }
+}
+
 // Pack the 16 partial points of every window slot (point 0 = B[0], point 1 + l = B[2^l]) in the
 // HOST TAIL's format: each coordinate re-based from the device's Montgomery radix 2^(29 NL) to
 // 2^(32 NW32) and written as NW32 little-endian u32 words, so the host does no conversion
