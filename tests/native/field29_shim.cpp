@@ -155,6 +155,25 @@ int shim_fp64_mul_both(const uint64_t* a6, const uint64_t* b6, uint64_t* out_adx
   return 0;
 #endif
 }
+// Host-field inversion: the plain integer inverse from the divstep iteration (fp64_host.hpp modinv62; returns 0 if it
+// did not come out), and both Montgomery-form inverses -- inv (divsteps, checked, Fermat as the fallback) and
+// inv_fermat -- of the same operand.  which = 0: the 377-bit base field (6 words), 1: the Edwards-BLS12 base field (4).
+int shim_fp64_inv(int which, const uint64_t* a, uint64_t* plain_inv, uint64_t* mont_inv, uint64_t* mont_inv_fermat) {
+  if (which == 0) {
+    Fp64::El x;
+    for (int i = 0; i < 6; i++) x.v[i] = a[i];
+    const int ok = Fp64::modinv62(x.v, plain_inv) ? 1 : 0;
+    const Fp64::El r = Fp64::inv(x), f = Fp64::inv_fermat(x);
+    for (int i = 0; i < 6; i++) mont_inv[i] = r.v[i], mont_inv_fermat[i] = f.v[i];
+    return ok;
+  }
+  Fq64::El x;
+  for (int i = 0; i < 4; i++) x.v[i] = a[i];
+  const int ok = Fq64::modinv62(x.v, plain_inv) ? 1 : 0;
+  const Fq64::El r = Fq64::inv(x), f = Fq64::inv_fermat(x);
+  for (int i = 0; i < 4; i++) mont_inv[i] = r.v[i], mont_inv_fermat[i] = f.v[i];
+  return ok;
+}
 void shim_g1_add(const uint32_t* a52, const uint32_t* b52, uint32_t* out52) { store_xyzz(g1_add(load_xyzz(a52), load_xyzz(b52)), out52); }
 void shim_g1_dbl(const uint32_t* a52, uint32_t* out52) { store_xyzz(g1_dbl(load_xyzz(a52)), out52); }
 // the 64-bit host-tail field through the same curve template

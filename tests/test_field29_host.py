@@ -263,6 +263,31 @@ def test_adx_multiplier_matches_the_portable_one(shim):
         pytest.skip("this CPU has no BMI2 / ADX: the portable multiplier is the only one")
 
 
+def test_divstep_inversion_matches_python_and_fermat(shim):
+    """csrc/fp64_host.hpp inv: the Bernstein-Yang divstep iteration (62 steps at a time, variable time) that replaced the
+    a^(p-2) exponentiation in the host tail and in the affine conversion's block inversion.  Its plain integer result
+    against Python's pow(a, -1, p), and the Montgomery-form inverse against the exponentiation's, for both host fields:
+    0 (no inverse: inv(0) = 0 like the exponentiation), 1, p - 1, small values, values around 2^62 k limb boundaries,
+    and random ones."""
+    rnd = random.Random(62)
+    for which, p, nw in ((0, R.P, 6), (1, R.Q, 4)):
+        special = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 62) - 1, 1 << 62, (1 << 62) + 1, (1 << 124) - 1, 1 << 124,
+                   (1 << 186) + 5, (1 << 248) - 1, p - (1 << 62), p - (1 << 124) + 1]
+        vals = [v % p for v in special] + [rnd.randrange(1, 1 << rnd.choice([8, 61, 63, 200, 250])) % p for _ in range(300)]
+        vals += [rnd.randrange(p) for _ in range(3000)]
+        mask = (1 << 64) - 1
+        for a in vals:
+            av = (ctypes.c_uint64 * nw)(*[(a >> (64 * i)) & mask for i in range(nw)])
+            plain, mont, fermat = ((ctypes.c_uint64 * nw)() for _ in range(3))
+            ok = shim.shim_fp64_inv(which, av, plain, mont, fermat)
+            assert list(mont) == list(fermat), hex(a)
+            if a == 0:
+                assert ok == 0 and all(w == 0 for w in mont)
+            else:
+                assert ok == 1, hex(a)
+                assert sum(int(w) << (64 * i) for i, w in enumerate(plain)) == pow(a, -1, p), hex(a)
+
+
 def test_lazy_bounds_proof():
     """tools/check_lazy_bounds.py: interval replay of the lazy formulas -- no 64-bit column can overflow, no limb
     of a limb-wise subtraction can go negative, results meet the storage invariant."""

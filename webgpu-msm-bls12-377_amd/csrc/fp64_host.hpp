@@ -199,7 +199,14 @@ struct FieldHost64 {
 #endif
     return mul_portable(a, b);
   }
-  static El inv(const El& a) {  // a^(p-2); p is odd and p = 1 mod 4 here, so only the low word changes
+  // ---- inversion ----
+  // inv_fermat: a^(p-2), ~570 products (16 us with the ADX multiplier).  inv: the same value by the Bernstein-Yang
+  // divstep iteration ("safegcd", variable time: nothing here is secret), 62 divsteps at a time on the low words of
+  // (f, g) = (p, a), the 2 x 2 transition matrix then applied to the full-size f, g and -- modulo p, with a Montgomery
+  // style exact division by 2^62 -- to the coefficients (d, e) that keep f = d a, g = e a (mod p): ~10 rounds of ~0.15 us
+  // for the 377-bit field.  The result is CHECKED (one product: a inv = 1) and falls back to inv_fermat if the check
+  // fails, so a mistake here can cost time, never a wrong result.  inv(0) = 0, like the exponentiation.
+  static El inv_fermat(const El& a) {  // a^(p-2); p is odd and p = 1 mod 4 here, so only the low word changes
     El r = one();
     for (int i = 64 * NW - 1; i >= 0; i--) {
       r = sqr(r);
@@ -207,6 +214,165 @@ struct FieldHost64 {
       if ((w >> (i & 63)) & 1) r = mul(r, a);
     }
     return r;
+  }
+  static constexpr int N62 = (64 * NW + 2 + 61) / 62;  // signed 62-bit limbs that hold |value| < 2 p (7 for 384 bits, 5 for 256)
+  typedef __int128 i128;
+  struct S62 {
+    int64_t v[N62];  // value = sum v[i] 2^(62 i); limbs 0 .. N62-2 in [0, 2^62), the top one carries the sign
+  };
+  static S62 to62(const uint64_t* w) {
+    S62 r;
+    for (int i = 0; i < N62; i++) {
+      const int bit = 62 * i, word = bit >> 6, off = bit & 63;
+      uint64_t x = word < NW ? w[word] >> off : 0;
+      if (off > 2 && word + 1 < NW) x |= w[word + 1] << (64 - off);
+      r.v[i] = (int64_t)(x & 0x3fffffffffffffffull);
+    }
+    return r;
+  }
+  static void from62(const S62& a, uint64_t* w) {  // a in [0, 2^(64 NW))
+    for (int i = 0; i < NW; i++) w[i] = 0;
+    for (int i = 0; i < N62; i++) {
+      const int bit = 62 * i, word = bit >> 6, off = bit & 63;
+      const uint64_t x = (uint64_t)a.v[i];
+      if (word < NW) w[word] |= x << off;
+      if (off > 2 && word + 1 < NW) w[word + 1] |= x >> (64 - off);
+    }
+  }
+  static bool is_zero62(const S62& a) {
+    int64_t acc = 0;
+    for (int i = 0; i < N62; i++) acc |= a.v[i];
+    return acc == 0;
+  }
+  static bool is_neg62(const S62& a) { return a.v[N62 - 1] < 0; }
+  // a += sign m (sign = +1 / -1), carries resolved; m has non-negative limbs
+  static void add_mod62(S62& a, const S62& m, int sign) {
+    int64_t carry = 0;
+    for (int i = 0; i < N62; i++) {
+      int64_t t = a.v[i] + (sign > 0 ? m.v[i] : -m.v[i]) + carry;
+      if (i + 1 < N62) {
+        carry = t >> 62;  // arithmetic shift: floor division
+        t &= 0x3fffffffffffffffll;
+      }
+      a.v[i] = t;
+    }
+  }
+  static bool geq62(const S62& a, const S62& m) {  // both non-negative with canonical limbs
+    for (int i = N62 - 1; i >= 0; i--) {
+      if (a.v[i] > m.v[i]) return true;
+      if (a.v[i] < m.v[i]) return false;
+    }
+    return true;
+  }
+  struct Trans {
+    int64_t u, v, q, r;  // 2^62 (f', g') = (u f + v g, q f + r g)
+  };
+  // 62 divsteps on the low 64 bits of f (odd) and g; delta as in Bernstein-Yang (starts at 1).
+  static int64_t divsteps62(int64_t delta, uint64_t f, uint64_t g, Trans& t) {
+    uint64_t u = 1, v = 0, q = 0, r = 1;  // two's complement
+    int i = 62;
+    for (;;) {
+      // a run of even g: g /= 2, the f row doubles (common scale 2^steps), delta += 1 each
+      const int zeros = __builtin_ctzll(g | (~0ull << i));  // at most i
+      g >>= zeros;
+      u <<= zeros;
+      v <<= zeros;
+      delta += zeros;
+      i -= zeros;
+      if (i == 0) break;
+      if (delta > 0) {  // (f, g) <- (g, (g - f) / 2)
+        delta = 1 - delta;
+        const uint64_t nf = g, ng = g - f, nu = q << 1, nv = r << 1, nq = q - u, nr = r - v;
+        f = nf, g = ng >> 1, u = nu, v = nv, q = nq, r = nr;
+      } else {  // g <- (g + f) / 2
+        delta = 1 + delta;
+        g = (g + f) >> 1;
+        q += u, r += v;
+        u <<= 1, v <<= 1;
+      }
+      i--;
+    }
+    t.u = (int64_t)u, t.v = (int64_t)v, t.q = (int64_t)q, t.r = (int64_t)r;
+    return delta;
+  }
+  static void update_fg62(S62& f, S62& g, const Trans& t) {
+    const int64_t M = 0x3fffffffffffffffll;
+    i128 cf = (i128)t.u * f.v[0] + (i128)t.v * g.v[0];
+    i128 cg = (i128)t.q * f.v[0] + (i128)t.r * g.v[0];
+    cf >>= 62, cg >>= 62;  // the low 62 bits are zero by construction
+    for (int i = 1; i < N62; i++) {
+      cf += (i128)t.u * f.v[i] + (i128)t.v * g.v[i];
+      cg += (i128)t.q * f.v[i] + (i128)t.r * g.v[i];
+      f.v[i - 1] = (int64_t)cf & M, cf >>= 62;
+      g.v[i - 1] = (int64_t)cg & M, cg >>= 62;
+    }
+    f.v[N62 - 1] = (int64_t)cf;
+    g.v[N62 - 1] = (int64_t)cg;
+  }
+  // (d, e) <- (u d + v e, q d + r e) / 2^62 mod m, for d, e in [0, m): add the multiple of m that clears the low 62 bits,
+  // shift, bring the result from (-m, 2 m) back into [0, m).
+  static void update_de62(S62& d, S62& e, const Trans& t, const S62& m, uint64_t m_inv62) {
+    const int64_t M = 0x3fffffffffffffffll;
+    i128 cd = (i128)t.u * d.v[0] + (i128)t.v * e.v[0];
+    i128 ce = (i128)t.q * d.v[0] + (i128)t.r * e.v[0];
+    const int64_t md = (int64_t)((0 - m_inv62 * (uint64_t)cd) & (uint64_t)M);
+    const int64_t me = (int64_t)((0 - m_inv62 * (uint64_t)ce) & (uint64_t)M);
+    cd += (i128)md * m.v[0], ce += (i128)me * m.v[0];
+    cd >>= 62, ce >>= 62;
+    S62 nd, ne;
+    for (int i = 1; i < N62; i++) {
+      cd += (i128)t.u * d.v[i] + (i128)t.v * e.v[i] + (i128)md * m.v[i];
+      ce += (i128)t.q * d.v[i] + (i128)t.r * e.v[i] + (i128)me * m.v[i];
+      nd.v[i - 1] = (int64_t)cd & M, cd >>= 62;
+      ne.v[i - 1] = (int64_t)ce & M, ce >>= 62;
+    }
+    nd.v[N62 - 1] = (int64_t)cd;
+    ne.v[N62 - 1] = (int64_t)ce;
+    if (is_neg62(nd)) add_mod62(nd, m, +1); else if (geq62(nd, m)) add_mod62(nd, m, -1);
+    if (is_neg62(ne)) add_mod62(ne, m, +1); else if (geq62(ne, m)) add_mod62(ne, m, -1);
+    d = nd, e = ne;
+  }
+  // out = x^-1 mod p as a plain integer; false if it did not come out (x = 0 mod p, or the round limit)
+  static bool modinv62(const uint64_t* x, uint64_t* out) {
+    const S62 m = to62(C::MOD);
+    uint64_t m_inv62 = C::MOD[0];  // Newton: the inverse of the odd low word modulo 2^64, then modulo 2^62
+    for (int k = 0; k < 6; k++) m_inv62 *= 2 - C::MOD[0] * m_inv62;
+    S62 f = m, g = to62(x), d, e;
+    for (int i = 0; i < N62; i++) d.v[i] = 0, e.v[i] = 0;
+    e.v[0] = 1;
+    if (is_zero62(g)) return false;
+    int64_t delta = 1;
+    for (int round = 0; round < 24 && !is_zero62(g); round++) {  // (49 x 384 + 57) / 17 divsteps bound any input: 18 rounds
+      Trans t;
+      const uint64_t f0 = (uint64_t)f.v[0] | ((uint64_t)f.v[1] << 62), g0 = (uint64_t)g.v[0] | ((uint64_t)g.v[1] << 62);
+      delta = divsteps62(delta, f0, g0, t);
+      update_de62(d, e, t, m, m_inv62);
+      update_fg62(f, g, t);
+    }
+    if (!is_zero62(g)) return false;
+    // f = +-1 (the gcd), d a = f (mod p)
+    bool plus = f.v[0] == 1, minus = f.v[0] == 0x3fffffffffffffffll;
+    for (int i = 1; i < N62; i++) {
+      plus = plus && f.v[i] == 0;
+      minus = minus && f.v[i] == (i + 1 < N62 ? 0x3fffffffffffffffll : -1);
+    }
+    if (!plus && !minus) return false;
+    if (minus && !is_zero62(d)) {  // d <- m - d
+      for (int i = 0; i < N62; i++) d.v[i] = -d.v[i];
+      add_mod62(d, m, +1);
+    }
+    from62(d, out);
+    return true;
+  }
+  static El inv(const El& a) {
+    if (is_zero(a)) return a;
+    static const El r3 = mul(from_const(C::R2), from_const(C::R2));  // R^3: (a R)^-1 = a^-1 R^-1 -> a^-1 R
+    El t;
+    if (modinv62(a.v, t.v)) {
+      const El r = mul(t, r3);
+      if (eq(mul(a, r), one())) return r;
+    }
+    return inv_fermat(a);
   }
   static El mul_sub_mul(const El& a, const El& b, const El& c, const El& d) { return sub(mul(a, b), mul(c, d)); }
   static El from_words32(const uint32_t* w) {  // 2 NW little-endian u32 words, already in this Montgomery form
