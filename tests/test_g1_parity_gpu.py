@@ -72,11 +72,12 @@ def test_ragged_sizes_against_oracle(engine, oracle, n, windows):
 
 
 def test_narrow_windows_edge_cases(engine, oracle, golden):
-    """The small-input path (22 signed 11-bit windows + an unsigned top window from bit 242, 2^11 buckets each) on the
-    inputs that stress a recode: every golden vector (edge scalars, cancellations, repeated points), digits at the
-    11-bit window boundaries (+-2^10, 2^10 - 1, 0), scalars of 2^253 and more (their top digit does not fit: the call
-    must rerun on the 16-bit path), one repeated base point, a skewed set that splits rows, and the scalar-overflow
-    error, which must fire exactly as on the main path."""
+    """The small-input path (eleven signed 12-bit windows + eleven unsigned 11-bit ones, the last from bit 242; 2^11
+    buckets each; kernels/decompose.hpp k_decompose_geom) on the inputs that stress a recode: every golden vector (edge
+    scalars, cancellations, repeated points), digits at the window boundaries of this geometry and of the one before it
+    (22 signed 11-bit windows + an unsigned top one, still there as MSM377_NARROW_EVEN=0), scalars of 2^253 and more
+    (their top digit does not fit: the call must rerun on the 16-bit path), one repeated base point, a skewed set that
+    splits rows, and the scalar-overflow error, which must fire exactly as on the main path."""
     engine.set_narrow_max(1 << 15)
     try:
         for name, case in golden.items():
@@ -88,6 +89,10 @@ def test_narrow_windows_edge_cases(engine, oracle, golden):
         full = lambda d: sum((d & 0x7FF) << (11 * w) for w in range(22))  # noqa: E731
         ks = [full(0x400), full(0x400), full(0x400), full(0x3FF), full(0x3FF), full(1), full(0x7FF), 0, R.R_ORDER - 1]
         assert engine.msm(R.encode_points(pts), R.encode_scalars(ks)) == R.encode_result(R.msm_naive(pts, ks))
+        # the same for the even geometry: d12 in every signed window, d11 in every unsigned one
+        even = lambda d12, d11: sum((d12 & 0xFFF) << (12 * w) for w in range(11)) + sum((d11 & 0x7FF) << (132 + 11 * w) for w in range(11))  # noqa: E731
+        ke = [even(0x800, 0x400), even(0x800, 0x7FF), even(0x7FF, 0x7FF), even(0x7FF, 1), even(0x801, 0), even(0xFFF, 0x3FF), even(1, 0x400), 0, even(0xFFF, 0x7FF) % R.R_ORDER]
+        assert engine.msm(R.encode_points(pts), R.encode_scalars(ke)) == R.encode_result(R.msm_naive(pts, ke))
         big = [(1 << 253) - 1, 1 << 253, (1 << 254) + 5, 1194 << 242, 2047 << 242, 2048 << 242, 12345, 1, R.R_ORDER - 2]
         assert engine.msm(R.encode_points(pts), R.encode_scalars(big)) == R.encode_result(R.msm_naive(pts, big))
         n = 3000
@@ -116,15 +121,16 @@ def test_narrow_windows_edge_cases(engine, oracle, golden):
         engine.set_bases(pl)
         assert engine.msm_fixed_base(same) == util.oracle_msm(oracle, pl, same)
         # an exceptional pair of the Edwards law meeting at the FIRST reduction level of the narrow geometry
-        # (buckets 0 and 1024 of the unsigned top window), in a bucket chain, and in the tail
+        # (buckets 0 and 1024 of the unsigned top window, bits 242..252 in both narrow geometries), in a bucket chain,
+        # and in the tail
         tp = util.t_prime()
         p = R.mul(R.G, 4711)
         q = R.add(p, tp)
         c = R.mul(R.G, 99)
-        a = R.add(R.mul(c, 1 << 11), tp)
+        a = R.add(R.mul(c, 1 << 12), tp)  # window 0 is 12 bits wide
         from webgpu_msm_bls12_377_amd.host.engine import FB_ACCUMULATE, FB_TAIL, FB_TREE
 
-        for pts2, ks2, where in (([p, q], [1 << 242, 1025 << 242], FB_TREE), ([p, q], [7, 7], FB_ACCUMULATE), ([c, a], [1 << 11, 1], FB_TAIL)):
+        for pts2, ks2, where in (([p, q], [1 << 242, 1025 << 242], FB_TREE), ([p, q], [7, 7], FB_ACCUMULATE), ([c, a], [1 << 12, 1], FB_TAIL)):
             before, _ = engine.fallback_info()
             assert engine.msm(R.encode_points(pts2), R.encode_scalars(ks2)) == R.encode_result(R.msm_naive(pts2, ks2))
             count, mask = engine.fallback_info()
@@ -740,6 +746,7 @@ def test_point_sharding_on_one_gpu(engine, oracle, world):
         {"MSM377_TAIL_THREADS": "8", "MSM377_TAIL_SPIN_US": "0", "MSM377_TAIL_NUMA": "0"},
         {"MSM377_TAIL_THREADS": "3"},
         {"MSM377_EVEN_WINDOWS": "0", "MSM377_TWIN_BATCH": "0"},  # sixteen equal windows everywhere; batches on one context
+        {"MSM377_NARROW_EVEN": "0", "MSM377_TAIL_LDS": "0"},  # small inputs: 22 signed 11-bit windows + an unsigned top one; reduction tail in global memory
         {"MSM377_NARROW_TAIL_FROM": "7", "MSM377_COOP_THREADS": "65536", "MSM377_NARROW_SEG": "32"},
         {"MSM377_NARROW_TAIL_FROM": "1", "MSM377_COOP_THREADS": "100000000"},  # every level on lane quads, everything behind level 0 in one launch
     ],

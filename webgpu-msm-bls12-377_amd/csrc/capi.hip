@@ -76,6 +76,7 @@ int msm377_ctx_create(int device, uint64_t max_points, msm377_ctx** out) {
   if (const char* e = getenv("MSM377_COOP_THREADS")) ctx->coop_threads = (uint32_t)atoi(e);
   if (const char* e = getenv("MSM377_NARROW_TAIL_FROM")) ctx->narrow_tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);
   if (const char* e = getenv("MSM377_TAIL_LDS")) ctx->tail_lds = atoi(e) != 0;
+  if (const char* e = getenv("MSM377_NARROW_EVEN")) ctx->narrow_even = atoi(e) != 0;
   if (const char* e = getenv("MSM377_EVEN_WINDOWS")) ctx->even_windows = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TWIN_BATCH")) ctx->twin_batches = atoi(e) != 0;
   if (const char* e = getenv("MSM377_TAIL_FROM")) ctx->tail_from = (uint32_t)std::min(std::max(atoi(e), 1), (int)TREE_LEVELS);

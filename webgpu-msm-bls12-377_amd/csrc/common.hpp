@@ -28,6 +28,10 @@ constexpr uint32_t NARROW_BITS = 11;       // digit width of the small-input pat
 constexpr uint32_t NARROW_LOG = 11;        // ... whose windows have 2^11 buckets (the unsigned top digit needs the room: k_decompose_narrow)
 constexpr uint32_t NARROW_SEG = 8;         // entries per accumulation work item on that path
 constexpr uint32_t NARROW_WINDOWS = 23;    // 22 signed 11-bit windows + the top window from bit 242 on
+// The same path in the even geometry (kernels/decompose.hpp k_decompose_geom; the default, MSM377_NARROW_EVEN): eleven signed
+// 12-bit windows, then eleven unsigned 11-bit ones, 11 x 12 + 11 x 11 = 253 bits, 2^11 buckets each.
+constexpr uint32_t NARROW_EVEN_WINDOWS = 22, NARROW_EVEN_SIGNED = 11, NARROW_EVEN_BITS = NARROW_LOG + 1;
+static_assert(NARROW_EVEN_SIGNED * NARROW_EVEN_BITS + (NARROW_EVEN_WINDOWS - NARROW_EVEN_SIGNED) * NARROW_LOG == 253, "the windows cover a 253-bit scalar");
 constexpr uint32_t MAX_WINDOW_SLOTS = NARROW_WINDOWS > MSM377_NUM_WINDOWS ? NARROW_WINDOWS : MSM377_NUM_WINDOWS;  // partial-record slots
 
 // ---- sort geometry (kernels/sort.hpp) ----

@@ -198,6 +198,7 @@ struct msm377_ctx {
   uint64_t narrow_max_points = 1ull << 16;
   // Batches on two sets of streams and buffers (sequencer.hip twin_prepare)
   bool tail_lds = true;         // MSM377_TAIL_LDS=0: the single-launch reduction tail works in global memory (k_reduce_tail)
+  bool narrow_even = true;      // MSM377_NARROW_EVEN=0: the small-input path recodes into 22 signed 11-bit windows + an unsigned top one (k_decompose_narrow)
   bool even_windows = true;     // MSM377_EVEN_WINDOWS=0: sixteen 16-bit windows on every path (kernels/decompose.hpp k_decompose)
   bool ed_equal_windows_once = false;  // ed_msm -> ed_msm_device: this call reruns a chunked upload whose scalars did not fit
   uint32_t acc_seq = 0;  // calls' accumulation kernels so far; h_out_flag[ACC_FLAG_WORD] follows it (k_merge_split_rows_quad)

@@ -149,6 +149,46 @@ __global__ void __launch_bounds__(256) k_decompose_narrow(const uint32_t* __rest
   if (carry16) atomicOr(err, ERR_SCALAR);
 }
 
+// The even geometry in general (k_decompose's `even` mode is the instance L = 15, a = 13, W = 16 with its fields at fixed
+// places): W windows of 2^L buckets over the 253 bits of a scalar below r -- the first `a` windows are SIGNED digits of
+// L + 1 bits (|d| <= 2^L, carry into the next window), the other W - a are UNSIGNED digits of L bits with a carry chain
+// of their own (limb + carry = 2^L -> digit 0, carry 1), and a (L + 1) + (W - a) L = 253, so that every window fills
+// its 2^L buckets with rows of n / 2^L entries.  The small-input path runs it with L = 11, a = 11, W = 22 (common.hpp
+// NARROW_EVEN_*): against k_decompose_narrow's 22 signed 11-bit windows + an unsigned top one, whose signed digits reach
+// only half of a window's 2048 buckets, that is one window less and rows half as long -- fewer rows cut into several
+// work items, a shorter merge.  Digits are stored biased by `bias` (2^L for k_small_sort).  A scalar whose top digit does
+// not fit -- everything from 2^253 on and the few below that carry out of the top window -- raises ERR_NARROW_RANGE and
+// the call reruns with sixteen 16-bit windows; the ERROR condition stays the 16-bit recode's (cuzk/utils.ts:95-98).
+__global__ void __launch_bounds__(256) k_decompose_geom(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t n, uint32_t L,
+                                                        uint32_t a, uint32_t W, uint32_t bias, int* __restrict__ err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words16(scalars + i * 8, w, 2);
+  uint32_t carry = 0, bit = 0;
+  for (uint32_t win = 0; win < W; win++) {
+    const uint32_t c = win < a ? L + 1 : L, word = bit >> 5, off = bit & 31;
+    uint32_t v = w[word] >> off;
+    if (off + c > 32 && word + 1 < 8) v |= w[word + 1] << (32 - off);
+    v = (v & ((1u << c) - 1u)) + carry;
+    uint32_t stored;
+    if (win < a) {
+      carry = v >> L ? 1u : 0u;  // v >= 2^L: the digit is v - 2^(L+1), in [-2^L, 0]
+      stored = v + bias - (carry << c);
+    } else {
+      carry = v >> L;  // v = 2^L: digit 0, carry on
+      stored = (v & ((1u << L) - 1u)) + bias;
+    }
+    digits[(size_t)win * n + i] = (uint16_t)stored;
+    bit += c;
+  }
+  if (carry | (w[7] >> 29)) atomicOr(err, ERR_NARROW_RANGE);  // bit == 253 here
+  uint32_t carry16 = 0;
+#pragma unroll
+  for (uint32_t win = 0; win < 16; win++) carry16 = (((w[win >> 1] >> (16 * (win & 1))) & 0xffffu) + carry16) >= 32768u ? 1u : 0u;
+  if (carry16) atomicOr(err, ERR_SCALAR);
+}
+
 // out[0..NA+NB) = a * b on 32-bit words (schoolbook, carries resolved per row).
 template <int NA, int NB_>
 __device__ __forceinline__ void mul_words(const uint32_t* a, const uint32_t* b, uint32_t* out) {

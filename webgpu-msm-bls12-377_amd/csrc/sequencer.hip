@@ -316,6 +316,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     StageTimer t(ctx, MSM377_STAGE_DECOMPOSE, st, part);
     if (wide)
       hipLaunchKernelGGL(k_decompose_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, ctx->d_wide_digits, n, d_err);
+    else if (narrow && ph.even)
+      hipLaunchKernelGGL(k_decompose_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, L, NARROW_EVEN_SIGNED, wc, 1u << L, d_err);
     else if (narrow)
       hipLaunchKernelGGL(k_decompose_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n, ph.cbits, L, wc, d_err);
     else if (glv)
@@ -678,7 +680,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
     bool even = ctx->even_windows && form != TABLE_TE_PRECOMP && !ctx->capture;  // (stage read-backs describe sixteen equal windows)
     for (;;) {
       uint32_t windows = MSM377_NUM_WINDOWS;
-      int cbits = MSM377_WINDOW_BITS, planes = MSM377_WINDOW_BITS - 1;
+      int cbits = MSM377_WINDOW_BITS, planes = MSM377_WINDOW_BITS - 1, short_from = 0;  // the host tail's view of the geometry
       ph.cbits = MSM377_WINDOW_BITS;
       ph.bucket_log = MSM377_WINDOW_BITS - 1;
       if (wide) {  // one window slot of 2^19 buckets over the 13-window table
@@ -688,14 +690,22 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
         windows = 1;
         cbits = WIDE_BITS;
         planes = WIDE_LOG;
-      } else if (narrow) {
+      } else if (narrow && even && ctx->narrow_even) {  // eleven signed 12-bit + eleven unsigned 11-bit windows
+        ph.cbits = NARROW_EVEN_BITS;
+        ph.bucket_log = NARROW_LOG;
+        windows = NARROW_EVEN_WINDOWS;
+        cbits = NARROW_EVEN_BITS;
+        planes = NARROW_LOG;
+        short_from = NARROW_EVEN_SIGNED;
+      } else if (narrow) {  // 22 signed 11-bit windows + an unsigned top one
         ph.cbits = NARROW_BITS;
         ph.bucket_log = NARROW_LOG;
         windows = NARROW_WINDOWS;
         cbits = NARROW_BITS;
         planes = NARROW_LOG;
       }
-      ph.even = even && !wide && !narrow && !table0;
+      ph.even = even && !wide && !table0 && (!narrow || ctx->narrow_even);
+      if (ph.even && !narrow) short_from = EVEN_FROM;
       ph.zc_out = true;
       int rc = form == TABLE_TE ? enqueue_windows<TeDev>(ctx, d_scalars, n, 0, windows, 0, false, ph)
                                 : enqueue_windows<TeDev, TeAffBase>(ctx, d_scalars, n, 0, windows, 0, false, ph);
@@ -707,8 +717,9 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       } else {
         HIP_TRY(ctx, hipEventSynchronize(ctx->done_ev[0]));
       }
-      if (narrow && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar >= 2^253: the 16-bit path takes it
+      if (narrow && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // a scalar >= 2^253: sixteen 16-bit windows take it
         narrow = false;
+        even = false;
         continue;
       }
       if (ph.even && (ctx->h_err[0] & ERR_NARROW_RANGE) && !(ctx->h_err[0] & ERR_SCALAR)) {  // likewise: sixteen equal windows take it
@@ -732,7 +743,7 @@ int g1_table_msm(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n, int for
       if (rc) return rc;
       auto t0 = std::chrono::steady_clock::now();
       const int tr = form == TABLE_TE_PRECOMP && !table0 ? (teh_combine(ctx->h_partials, 1, out_xy, cbits, planes) ? TAIL_EXCEPTIONAL : TAIL_OK)
-                                              : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes, ph.even ? (int)EVEN_FROM : 0);
+                                              : te_tail(ctx, ctx->h_partials, out_xy, (int)windows, cbits, planes, short_from);
       time_tail(ctx, t0);
       if (tr < 0) return tr;
       if (tr == TAIL_EXCEPTIONAL) note_fallback(ctx, MSM377_FB_TAIL);
