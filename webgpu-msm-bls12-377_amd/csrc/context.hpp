@@ -151,7 +151,7 @@ struct msm377_ctx {
   // MSM377_NARROW_TAIL_FROM: tail_from of the narrow-window path (2048 buckets per window).  Reduce stage at 2^12 with
   // 7 / 5 / 4 / 3 / 2: 0.106 / 0.099 / 0.096 / 0.101 / 0.122 ms (profiles/r02_final/ab_narrow_tree.txt).
   uint32_t narrow_tail_from = 4;
-  uint32_t narrow_seg = NARROW_SEG;  // MSM377_NARROW_SEG (>= NARROW_SEG: the buffers are sized for that)
+  uint32_t narrow_seg = 0;  // MSM377_NARROW_SEG (>= NARROW_SEG: the buffers are sized for that); 0 = by input size (enqueue_part)
   uint64_t narrow_quad_items = 100000;  // MSM377_NARROW_QUAD_ITEMS: most work items k_accumulate_quad is used for
   int narrow_quad_acc = 1;         // MSM377_NARROW_QUAD_ACC=0: the narrow-window path accumulates with a thread per work item, like the main path
   // First level of the single-launch tail of the reduction (k_reduce_tail); MSM377_TAIL_FROM, 15 = one launch per level throughout.

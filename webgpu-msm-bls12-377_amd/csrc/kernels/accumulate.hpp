@@ -310,13 +310,13 @@ __global__ void __launch_bounds__(256, 2) k_merge_split_rows_quad(const uint32_t
     const uint32_t len = row_len(row_ptr, L, row, rv);
     const uint32_t nseg = row_split(len, SEG).nseg;
     const uint32_t ws = row >> L, t = row & ((1u << L) - 1);
-    typename CV::Pt acc = load_bucket<CV>(buckets, L, ws, t);
+    typename CV::Pt acc = load_bucket_quad<CV>(buckets, L, ws, t, q);  // (all four lanes of a quad share i: they are all here)
     const uint32_t* src = ovf + (size_t)row_ovf_base[row] * CV::BKT_WORDS;
-    typename CV::Pt nxt = load_record<CV>(src);
+    typename CV::Pt nxt = load_record_quad<CV>(src, q);
     bool bad = false;
     for (uint32_t s = 1; s < nseg; s++) {
       const typename CV::Pt cur = nxt;
-      if (s + 1 < nseg) nxt = load_record<CV>(src + (size_t)s * CV::BKT_WORDS);
+      if (s + 1 < nseg) nxt = load_record_quad<CV>(src + (size_t)s * CV::BKT_WORDS, q);
       acc = add_quad(acc, cur, q);
       bad |= CV::is_bad(acc);
     }

@@ -92,6 +92,39 @@ __device__ __forceinline__ Limbs<NLIMB> quad_bcast(const Limbs<NLIMB>& v) {
 #endif
   return r;
 }
+// A bucket record read by a lane quad: lane q fetches coordinate q (one 64-byte slot) and the four lanes exchange what they
+// got -- a quarter of the memory traffic of four lanes each reading the whole record (the merge of split rows moved
+// 150 MB that way at 2^16 points, 90 us for 135 k additions).  All four lanes of the quad must be here.
+template <class CV>
+__device__ __forceinline__ typename CV::Pt load_record_quad(const uint32_t* __restrict__ p, uint32_t q) {
+  constexpr uint32_t NL = CV::NL;
+  typename CV::F::El mine;
+  const uint32_t* slot = p + q * CV::COORD_WORDS;
+  const uint4* s4 = reinterpret_cast<const uint4*>(slot);
+#pragma unroll
+  for (uint32_t k = 0; k < NL / 4; k++) {
+    const uint4 v = s4[k];
+    mine.l[4 * k + 0] = v.x;
+    mine.l[4 * k + 1] = v.y;
+    mine.l[4 * k + 2] = v.z;
+    mine.l[4 * k + 3] = v.w;
+  }
+  mine.l[NL - 1] = slot[NL - 1];
+  const typename CV::F::El c0 = quad_bcast<0>(mine), c1 = quad_bcast<1>(mine), c2 = quad_bcast<2>(mine), c3 = quad_bcast<3>(mine);
+  uint32_t w[CV::PT_WORDS];
+#pragma unroll
+  for (uint32_t j = 0; j < NL; j++) {
+    w[j] = c0.l[j];
+    w[NL + j] = c1.l[j];
+    w[2 * NL + j] = c2.l[j];
+    w[3 * NL + j] = c3.l[j];
+  }
+  return CV::from_words(w);
+}
+template <class CV>
+__device__ __forceinline__ typename CV::Pt load_bucket_quad(const uint32_t* __restrict__ b, uint32_t L, uint32_t ws, uint32_t t, uint32_t q) {
+  return load_record_quad<CV>(bucket_ptr<CV>(b, L, ws, t), q);
+}
 template <int NLIMB>
 __device__ __forceinline__ Limbs<NLIMB> sel4(uint32_t q, const Limbs<NLIMB>& a0, const Limbs<NLIMB>& a1, const Limbs<NLIMB>& a2, const Limbs<NLIMB>& a3) {
   Limbs<NLIMB> r;
@@ -169,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) k_tree_step_quad(uint32_t* __restrict_
   const uint32_t oi = g / half, kk = g % half;
   const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
   const uint32_t x = lo + kk, y = x + half;
-  const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, L, ws, x), load_bucket<CV>(buckets, L, ws, y), q);
+  const typename CV::Pt sum = add_quad(load_bucket_quad<CV>(buckets, L, ws, x, q), load_bucket_quad<CV>(buckets, L, ws, y, q), q);
   if (CV::is_bad(sum)) atomicOr(err, ERR_TE_TREE);
   // each lane stores one coordinate
   const typename CV::F::El c = coord4(q, sum);
@@ -245,7 +278,7 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_reduce_tail(uint32_t* __res
       const uint32_t oi = job < first ? job + 1 : (li == 0 ? 0u : first + li);
       const uint32_t lo = oi == 0 ? 0u : (NB >> oi);
       const uint32_t x = lo + kk, y = x + half;
-      const typename CV::Pt sum = add_quad(load_bucket<CV>(buckets, L, ws, x), load_bucket<CV>(buckets, L, ws, y), q);
+      const typename CV::Pt sum = add_quad(load_bucket_quad<CV>(buckets, L, ws, x, q), load_bucket_quad<CV>(buckets, L, ws, y, q), q);
       bad |= CV::is_bad(sum);
       store_coord<CV>(bucket_ptr<CV>(buckets, L, ws, x) + q * CV::COORD_WORDS, coord4(q, sum).l);
     }

@@ -283,7 +283,10 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
   // per launch: each part must fill the GPU on its own.  Narrow windows: a small input is all latency -- a work item is
   // a serial chain of ~10 us additions -- so its chains are cut at 8 entries (the buffers, sized for 16 windows of
   // 2^15 rows plus entries / SEG_MIN items, hold the 23 x 2^11 rows and 23 n / 8 items of an input this small easily).
-  const uint32_t SEG = (narrow && !ctx->seg_plain) ? ctx->narrow_seg : auto_seg(ctx, entries, glv);
+  // (With the even geometry and quad-cooperative record loads in the merge, 16 entries win from 2^14 points on and 12
+  // at 2^13 -- accumulate + merge 0.288 / 0.277 / 0.284 / 0.270 ms for 8 / 10 / 12 / 16 at 2^16, 0.077 / 0.077 / 0.074 /
+  // 0.085 at 2^13, profiles/r03_final/sweep_narrow_seg_even.txt; below that a row has two entries on average.)
+  const uint32_t SEG = (narrow && !ctx->seg_plain) ? (ctx->narrow_seg ? ctx->narrow_seg : (n > 8192 ? 16u : 12u)) : auto_seg(ctx, entries, glv);
   uint16_t* digits = ctx->d_digits + (size_t)pv.ws0 * n;
   uint32_t* range_counts = ctx->d_range_counts + (size_t)part * NRANGE * (MAX_SORT_BLOCKS / 2);
   uint32_t* region_base = ctx->d_region_base + (size_t)pv.ws0 * (NRANGE + 1);
