@@ -227,7 +227,8 @@ int msm377_ctx_set_glv(msm377_ctx* ctx, int mode);
 int msm377_ctx_set_g1_form(msm377_ctx* ctx, int form);
 
 /* Small inputs: G1 full-MSM calls of at most `max_points` points (default and at most 2^16; 0 = never) run with
- * 11-bit windows -- 23 windows of 2 048 buckets instead of 16 of 32 768: 0.25-0.56 instead of 0.52-0.60 ms -- the
+ * narrow windows -- 22 windows of 2 048 buckets (eleven signed 12-bit and eleven unsigned 11-bit digits per scalar)
+ * instead of 16 of 32 768: 0.22-0.53 instead of 0.52-0.60 ms -- the
  * counterpart of the reference's switch to narrower windows for small inputs (src/submission/submission.ts:97: 4-bit
  * below 65 536 points).  Same results, and the error condition of the 16-bit recode for every input size (the reference's own
  * 4-bit branch rejects more NON-canonical scalars, k > 0x777...7; every k < r passes both); scalars of 2^253 and more rerun

@@ -6,7 +6,7 @@
 // Pipeline (each stage names the reference code it replaces; paths relative to /root/reference/src/submission/):
 //   kernels/convert.hpp     k_affine_up / host inversion / k_affine_down (n >= 2^20, resident tables), k_convert_bases (otherwise)
 //                           wire x||y -> Montgomery records            wgsl/cuzk/convert_point_coords_and_decompose_scalars.template.wgsl:41-99 + barrett.template.wgsl:60-82
-//   kernels/decompose.hpp   k_decompose (16-bit windows), k_decompose_narrow (inputs <= 2^16 points: 11-bit windows, submission.ts:97)
+//   kernels/decompose.hpp   k_decompose (16 windows), k_decompose_geom / k_decompose_narrow (inputs <= 2^16 points: 22 / 23 windows of 2^11 buckets, submission.ts:97)
 //                           scalars -> signed digits                   same file :100-141; model cuzk/utils.ts:66-109
 //   kernels/sort.hpp        k_range_count / k_range_scan / k_partition / k_local_sort (k_small_sort on the narrow path)
 //                           per-window counting sort -> CSR            wgsl/cuzk/transpose_serial.wgsl:34-76 (16 serial threads there); model cuzk/transpose.ts:14-62

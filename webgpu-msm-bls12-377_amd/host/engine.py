@@ -393,7 +393,7 @@ class MsmEngine:
         return int(self._lib.msm377_ctx_get_stage_form(self._ctx))
 
     def set_narrow_max(self, max_points: int = 1 << 16):
-        """Inputs of at most this many points run with 11-bit windows (msm377_ctx_set_narrow_max; 0 = never)."""
+        """Inputs of at most this many points run with narrow windows of 2^11 buckets (msm377_ctx_set_narrow_max; 0 = never)."""
         self._check(self._lib.msm377_ctx_set_narrow_max(self._ctx, int(max_points)), "msm377_ctx_set_narrow_max")
 
     def set_g1_form(self, form="edwards"):
