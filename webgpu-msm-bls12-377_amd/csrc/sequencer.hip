@@ -460,13 +460,8 @@ int enqueue_part(msm377_ctx* ctx, const uint32_t* d_scalars, uint64_t n_scalars,
     if constexpr (CV::HAS_QUAD) {
       if (tail_from < levels) {
         const size_t lds_bytes = (size_t)(NB >> tail_from) * CV::PT_WORDS * 4;  // the stretch of buckets a workgroup works on
-        if (ctx->tail_lds && lds_bytes > 64 * 1024 && lds_bytes <= TAIL_LDS_BYTES_MAX) {
-          static bool raised = false;  // per curve policy (this is a template)
-          if (!raised) {
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reduce_tail_lds<CV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS_BYTES_MAX));
-            raised = true;
-          }
-        }
+        if (ctx->tail_lds && lds_bytes > 64 * 1024 && lds_bytes <= TAIL_LDS_BYTES_MAX)  // (only with MSM377_TAIL_FROM below its default; per device, so every time)
+          HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reduce_tail_lds<CV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS_BYTES_MAX));
         if (ctx->tail_lds && lds_bytes <= TAIL_LDS_BYTES_MAX)
           hipLaunchKernelGGL(k_reduce_tail_lds<CV>, dim3(tail_from + 1, wc), dim3(TAIL_THREADS), lds_bytes, st, buckets, L, tail_from, d_err);
         else
