@@ -174,6 +174,18 @@ int shim_fp64_inv(int which, const uint64_t* a, uint64_t* plain_inv, uint64_t* m
   for (int i = 0; i < 4; i++) mont_inv[i] = r.v[i], mont_inv_fermat[i] = f.v[i];
   return ok;
 }
+// The host tail's Horner chain over window records in a given window geometry (fp64_host.hpp teh_combine / g1h_combine /
+// tail_position): num_windows records of 16 points x 48 words, windows of cbits bits with `planes` bit-plane sums each,
+// the windows from short_from on one bit shorter (0: all alike).  form 0: Edwards records (returns 1 on an exceptional
+// case), 1: Weierstrass records (16-bit windows only).  pieces > 1: the chain cut the way the threaded tail cuts it.
+int shim_tail_combine_geom(const uint32_t* partials, int num_windows, int cbits, int planes, int short_from, int form, uint8_t* out96) {
+  if (form == 1) {
+    g1h_combine(partials, num_windows, out96, short_from);
+    return 0;
+  }
+  return teh_combine(partials, num_windows, out96, cbits, planes, short_from) ? 1 : 0;
+}
+int shim_tail_positions(int num_windows, int cbits, int short_from) { return tail_positions(num_windows, cbits, short_from); }
 void shim_g1_add(const uint32_t* a52, const uint32_t* b52, uint32_t* out52) { store_xyzz(g1_add(load_xyzz(a52), load_xyzz(b52)), out52); }
 void shim_g1_dbl(const uint32_t* a52, uint32_t* out52) { store_xyzz(g1_dbl(load_xyzz(a52)), out52); }
 // the 64-bit host-tail field through the same curve template

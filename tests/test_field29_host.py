@@ -288,6 +288,51 @@ def test_divstep_inversion_matches_python_and_fermat(shim):
                 assert sum(int(w) << (64 * i) for i, w in enumerate(plain)) == pow(a, -1, p), hex(a)
 
 
+def test_host_tail_in_the_even_window_geometries(shim):
+    """csrc/fp64_host.hpp tail_position / teh_combine / g1h_combine with `short_from`: the host tail of a whole MSM on the
+    main path (thirteen 16-bit windows, then three 15-bit ones: bit offsets 208, 223, 238), of the small-input path
+    (eleven 12-bit windows, then eleven 11-bit ones, 11 bit planes) and of the uniform layouts, against the definition
+    sum_w 2^(offset_w) (Sum_w + sum_l 2^l Plane_{w,l}) computed with Python integers.  Records as the GPU writes them
+    (16 points per window; planes beyond the geometry's count hold garbage that must not be read)."""
+    import struct
+
+    rnd = random.Random(253)
+    base = [R.mul(R.G, rnd.randrange(1, R.R_ORDER)) for _ in range(9)]
+
+    def case(num_windows, cbits, planes, short_from, form):
+        recs, expect, offset = [], None, 0
+        for w in range(num_windows):
+            width = cbits - 1 if (short_from and w >= short_from) else cbits
+            pts16 = [rnd.choice(base + [None]) for _ in range(max(16, planes + 1))]  # (the wide table's one record has 20 points)
+            g = pts16[0]
+            for l in range(planes):
+                if l < width:  # a plane at or beyond the window's width is never produced by the reduction: leave it out of the sum ...
+                    g = R.add(g, R.mul(pts16[1 + l], 1 << l))
+                else:
+                    pts16[1 + l] = None  # ... and out of the record
+            words = []
+            for i, pt in enumerate(pts16):
+                z = rnd.randrange(1, R.P)
+                words += util.record_point_words(pt, z) if form == 1 else util.te_record_point_words(pt, z, tag=(i == 0))
+            recs.append(struct.pack("<%dI" % len(words), *words))
+            expect = R.add(expect, R.mul(g, 1 << offset))
+            offset += width
+        assert shim.shim_tail_positions(num_windows, cbits, short_from) == offset
+        buf = b"".join(recs)
+        arr = (ctypes.c_uint32 * (len(buf) // 4)).from_buffer_copy(buf)
+        out = ctypes.create_string_buffer(96)
+        assert shim.shim_tail_combine_geom(arr, num_windows, cbits, planes, short_from, form, out) == 0
+        assert out.raw == R.encode_result(expect), (num_windows, cbits, planes, short_from, form)
+        return offset
+
+    assert case(16, 16, 15, 13, 0) == 253  # whole MSMs on the main path
+    assert case(16, 16, 15, 13, 1) == 253  # the same chain over Weierstrass records
+    assert case(22, 12, 11, 11, 0) == 253  # the small-input path
+    assert case(16, 16, 15, 0, 0) == 256  # sixteen equal windows (window shards, the fallback for scalars >= 2^253)
+    assert case(23, 11, 11, 0, 0) == 253  # the small-input path's first geometry
+    assert case(1, 20, 19, 0, 0) == 20  # one record of the wide-window table
+
+
 def test_lazy_bounds_proof():
     """tools/check_lazy_bounds.py: interval replay of the lazy formulas -- no 64-bit column can overflow, no limb
     of a limb-wise subtraction can go negative, results meet the storage invariant."""
