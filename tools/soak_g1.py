@@ -15,9 +15,9 @@ os.environ.update({"MSM377_UPLOAD_SORT_ONCE": "1", "MSM377_UPLOAD_CHUNKS": "6", 
 eng_once = msm.MsmEngine(1 << 17)
 for k in ("MSM377_UPLOAD_SORT_ONCE", "MSM377_UPLOAD_CHUNKS", "MSM377_UPLOAD_SPLIT"):
     del os.environ[k]
-rnd = random.Random(20261004)
+rnd = random.Random(int(os.environ.get("SOAK_SEED", "20261004")))
 t0 = time.time(); bad = 0; cases = 0
-while time.time() - t0 < 150:
+while time.time() - t0 < float(os.environ.get("SOAK_SECONDS", "150")):
     n = rnd.choice([1, 2, 3, 5, 17, 64, 65, 255, 256, 257, 1000, 2999, 3000, 3001, 4096, 10000, 33333, 65536, 100003])
     seed = rnd.randrange(1 << 30)
     r2 = random.Random(seed)
