@@ -519,6 +519,17 @@ def test_points_outside_the_prime_order_subgroup(engine, oracle):
         assert engine.msm_fixed_base(sb) == exp, name  # the table stays in the form it fell back to
         d_s = dev(sb + sb)
         assert engine.msm_fixed_base_batch_device(d_s.data_ptr(), n, 2) == [exp, exp], name
+        # a fresh Edwards table and a batch large enough to run as two halves on the twin context: whichever half meets
+        # the exceptional case, the whole batch reruns on the Weierstrass table; the same over both precomputed tables
+        for bits in (0, 16, 20):
+            if bits:
+                engine.set_precompute_window(bits)
+                engine.set_bases_precomputed(pb)
+            else:
+                engine.set_bases(pb)
+            d_b = dev(sb * 5)
+            assert engine.msm_fixed_base_batch_device(d_b.data_ptr(), n, 5) == [exp] * 5, (name, bits)
+        engine.set_precompute_window(16)
     # P - (P + T2) = -T2: opposite signs of the same digit
     pts = [rnd_pts[0], shifted[0]]
     ks = [7, R.R_ORDER - 7]
