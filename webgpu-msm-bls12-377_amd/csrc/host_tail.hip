@@ -43,8 +43,11 @@ template <class Pt, class Extra, class PieceFn, class AddFn>
 int tail_horner_mt(msm377_ctx* ctx, PieceFn piece, AddFn add, int positions, Pt* out, std::shared_ptr<TailState<Pt, Extra>> st) {
   constexpr int MAXC = TailPool::WORKERS + 1;
   TailPool& pool = ctx->tail_pool;
-  const int used = tail_split(positions, std::max(1, std::min(ctx->tail_threads, MAXC)), st->bounds);
-  if (used > 1) pool.start();
+  const int want = std::max(1, std::min(ctx->tail_threads, MAXC));
+  if (want > 1) pool.start();
+  int worker_of[MAXC];  // helper threads that are free to take a piece (one that still holds a job it never started is not)
+  const int helpers = want > 1 ? pool.idle_workers(worker_of, want - 1) : 0;
+  const int used = tail_split(positions, helpers + 1, st->bounds);
   // MSM377_TAIL_TRACE=1: per-piece start / end (us after the call) and CPU, on stderr
   const bool trace = ctx->tail_trace;
   const int64_t t_call = trace ? TailPool::now_ns() : 0;
@@ -53,11 +56,13 @@ int tail_horner_mt(msm377_ctx* ctx, PieceFn piece, AddFn add, int positions, Pt*
     st->part[k] = piece(*st, st->bounds[k], st->bounds[k + 1], k);
     if (trace) st->mark[k].t1 = TailPool::now_ns();
   };
-  for (int k = 0; k + 1 < used; k++) pool.post(k, [chain, k] { chain(k); });
+  // pieces are shares (tail_pool.hpp): a piece whose helper has not touched it when the caller gets to it runs here
+  auto shares = std::make_shared<TailPool::Shares>();
+  for (int k = 0; k + 1 < used; k++) pool.post_share(worker_of[k], shares, k, [chain, k] { chain(k); });
   chain(used - 1);  // the top piece: the fewest positions, the most doublings
   Pt acc = st->part[used - 1];
   for (int k = used - 2; k >= 0; k--) {
-    if (!pool.wait(k)) return worker_timeout(ctx);
+    if (!pool.finish_share(shares, k, [chain, k] { chain(k); })) return worker_timeout(ctx);
     acc = add(*st, acc, st->part[k], used - 1);
   }
   if (trace) {
@@ -160,13 +165,17 @@ int invert_block_products_mt(msm377_ctx* ctx, uint32_t b0, uint32_t b1) {
   if (nblk >= 32 && !single_threaded(ctx)) {
     TailPool& pool = ctx->tail_pool;
     pool.start();
-    const int parts = std::min(ctx->tail_threads, TailPool::WORKERS + 1);
+    int worker_of[TailPool::WORKERS + 1];
+    const int parts = 1 + pool.idle_workers(worker_of, std::min(ctx->tail_threads, TailPool::WORKERS + 1) - 1);
     const uint32_t per = (nblk + parts - 1) / parts;
-    for (int k = 0; k + 1 < parts; k++)
-      pool.post(k, [ctx, k, per, b0, b1] { invert_block_products(ctx, std::min(b1, b0 + (uint32_t)(k + 1) * per), std::min(b1, b0 + (uint32_t)(k + 2) * per)); });
+    // shares (tail_pool.hpp): the caller takes over a range whose helper has not started on it.  A helper that comes back
+    // late finds its share claimed and touches nothing of this call (ctx->aff_scratch, h_aff_inv belong to the next one by then).
+    auto shares = std::make_shared<TailPool::Shares>();
+    auto range = [ctx, per, b0, b1](int k) { invert_block_products(ctx, std::min(b1, b0 + (uint32_t)(k + 1) * per), std::min(b1, b0 + (uint32_t)(k + 2) * per)); };
+    for (int k = 0; k + 1 < parts; k++) pool.post_share(worker_of[k], shares, k, [range, k] { range(k); });
     invert_block_products(ctx, b0, std::min(b1, b0 + per));
     for (int k = 0; k + 1 < parts; k++)
-      if (!pool.wait(k)) return worker_timeout(ctx);
+      if (!pool.finish_share(shares, k, [range, k] { range(k); })) return worker_timeout(ctx);
   } else {
     invert_block_products(ctx, b0, b1);
   }

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -137,6 +138,55 @@ struct TailPool {
     if (slot[k].done.load(std::memory_order_acquire) == want) return true;
     const int64_t t0 = now_ns();
     for (uint32_t spins = 0; slot[k].done.load(std::memory_order_acquire) != want; spins++) {
+      __builtin_ia32_pause();
+      if ((spins & 0x3ff) == 0x3ff && now_ns() - t0 > wait_limit_ns) {
+        poisoned.store(true);
+        return false;
+      }
+    }
+    return true;
+  }
+  // ---- shares: jobs that either a worker or the caller runs, exactly once ----
+  // A helper thread that has lost its CPU (a busy box, another tenant) comes back milliseconds late; a call that waits
+  // for it turns a 60 us tail into a 3 ms one, and one such step in twenty moves a benchmark's mean by 5 %.  So a call's
+  // shares are CLAIMED: whoever gets to a share first -- its worker, or the caller when it reaches that share in its own
+  // order and finds it untouched -- runs it, the other side skips it.  A worker that is still holding an earlier,
+  // never-started job is not `idle` and gets no share until it has come back and dropped that job.
+  struct Shares {
+    std::atomic<int> state[WORKERS + 1];  // 0 unclaimed, 1 running, 2 done
+    Shares() {
+      for (auto& a : state) a.store(0, std::memory_order_relaxed);
+    }
+  };
+  bool idle(int k) const { return slot[k].done.load(std::memory_order_acquire) == slot[k].posted.load(std::memory_order_acquire); }
+  // The workers that can take a share now (at most `want`), in slot order.
+  int idle_workers(int* out, int want) const {
+    int n = 0;
+    for (int k = 0; k < WORKERS && n < want; k++)
+      if (idle(k)) out[n++] = k;
+    return n;
+  }
+  // f must own (by value / shared_ptr) everything it touches: a late worker may still call it after the caller has
+  // left -- it then finds the share claimed and returns without touching anything but `sh`.
+  void post_share(int worker, std::shared_ptr<Shares> sh, int j, std::function<void()> f) {
+    post(worker, [sh, j, f] {
+      int expect = 0;
+      if (sh->state[j].compare_exchange_strong(expect, 1)) {
+        f();
+        sh->state[j].store(2, std::memory_order_release);
+      }
+    });
+  }
+  // The caller's side of share j: run it if nobody has, else wait for whoever runs it (bounded like wait()).
+  bool finish_share(const std::shared_ptr<Shares>& sh, int j, const std::function<void()>& f) {
+    int expect = 0;
+    if (sh->state[j].compare_exchange_strong(expect, 1)) {
+      f();
+      sh->state[j].store(2, std::memory_order_release);
+      return true;
+    }
+    const int64_t t0 = now_ns();
+    for (uint32_t spins = 0; sh->state[j].load(std::memory_order_acquire) != 2; spins++) {
       __builtin_ia32_pause();
       if ((spins & 0x3ff) == 0x3ff && now_ns() - t0 > wait_limit_ns) {
         poisoned.store(true);
