@@ -83,33 +83,36 @@ int h2d_staged(msm377_ctx* ctx, void* d_dst, const uint8_t* src, size_t bytes, s
     HIP_TRY(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));  // fall back to the runtime's pageable path
     return MSM377_OK;
   }
-  // Pieces of about 4 MB, their number a multiple of the worker count: every worker copies the same amount (with
-  // fixed 8 MB pieces a 48 MB upload took as long as a 64 MB one), and a worker's host copy of piece k+1 overlaps
-  // the DMA of piece k.
+  // Pieces of about 4 MB, their number a multiple of the worker count (with fixed 8 MB pieces a 48 MB upload took as
+  // long as a 64 MB one); a thread's host copy of its next piece overlaps the DMA of the one before.  The pieces are
+  // CLAIMED from a counter, by the NT workers and by the calling thread alike: every thread ends up with the same
+  // amount when all run, and a worker that has lost its CPU leaves its pieces to the others instead of holding up the call.
   size_t npieces = (bytes + PIECE - 1) / PIECE;
   npieces = (npieces + NT - 1) / NT * NT;
   const size_t piece = ((bytes + npieces - 1) / npieces + 4095) & ~(size_t)4095;
   uint8_t* stage = ctx->h_stage + stage_off;
-  hipError_t errs[NT_MAX];
+  hipError_t errs[NT_MAX + 1];
   std::thread workers[NT_MAX];
   const int device = ctx->device;
-  for (int t = 0; t < NT; t++) {
-    errs[t] = hipSuccess;
-    workers[t] = std::thread([=, &errs] {
-      hipError_t e = hipSetDevice(device);
-      for (size_t c = t; c < npieces && e == hipSuccess; c += NT) {
-        const size_t off = c * piece;
-        if (off >= bytes) break;
-        const size_t len = (bytes - off < piece) ? bytes - off : piece;
-        memcpy(stage + off, src + off, len);
-        e = hipMemcpyAsync((uint8_t*)d_dst + off, stage + off, len, hipMemcpyHostToDevice, ctx->copy_stream[t]);
-      }
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream[t]);
-      errs[t] = e;
-    });
-  }
+  std::atomic<size_t> next{0};
+  auto copy_pieces = [&, device](int t) {  // t: this thread's copy stream
+    hipError_t e = hipSetDevice(device);
+    for (;;) {
+      const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+      const size_t off = c * piece;
+      if (c >= npieces || off >= bytes || e != hipSuccess) break;
+      const size_t len = (bytes - off < piece) ? bytes - off : piece;
+      memcpy(stage + off, src + off, len);
+      e = hipMemcpyAsync((uint8_t*)d_dst + off, stage + off, len, hipMemcpyHostToDevice, ctx->copy_stream[t]);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream[t]);
+    errs[t] = e;
+  };
+  for (int t = 0; t <= NT; t++) errs[t] = hipSuccess;
+  for (int t = 0; t < NT; t++) workers[t] = std::thread([&copy_pieces, t] { copy_pieces(t); });
+  copy_pieces(NT);  // the caller takes pieces too (its own stream)
   for (int t = 0; t < NT; t++) workers[t].join();
-  for (int t = 0; t < NT; t++) HIP_TRY(ctx, errs[t]);
+  for (int t = 0; t <= NT; t++) HIP_TRY(ctx, errs[t]);
   return MSM377_OK;
 }
 
