@@ -541,12 +541,12 @@ def main():
             r2 = eng.msm(points_host, scalars_host)
             out["ms_incl_h2d_first_call"] = round((time.perf_counter() - t1) * 1e3, 3)
             samples = []
-            for _ in range(5):  # chunked upload overlapped with the computation (msm377_g1_msm); median of 5 calls
+            for _ in range(15):  # chunked upload overlapped with the computation (msm377_g1_msm); median of 15 calls
                 t1 = time.perf_counter()
                 r2 = eng.msm(points_host, scalars_host)
                 samples.append((time.perf_counter() - t1) * 1e3)
                 assert r2 == result
-            out["ms_incl_h2d"] = round(sorted(samples)[2], 3)
+            out["ms_incl_h2d"] = round(sorted(samples)[len(samples) // 2], 3)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import util  # the CPU oracle: checker + cpu_baseline leg only
 
